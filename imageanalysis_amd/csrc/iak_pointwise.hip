@@ -1,0 +1,405 @@
+// Per-pixel (no neighbourhood) kernels: colour conversion, histogram, look-up family,
+// noise application.  All are HBM-bound byte streams: every lane moves 16 pixels per
+// load/store (one dwordx4), a workgroup is 256 lanes (4 waves), the grid is
+// (blocks per image, B) with a grid-stride loop inside the image.
+#include "iak_common.hpp"
+
+namespace iak {
+
+// ---------------------------------------------------------------------------------------
+// Generic 16-pixels-per-lane streaming pass.  F provides
+//   void begin(int b)                       per-image set-up (may use LDS + __syncthreads)
+//   u32x4 apply16(u32x4 px, long long off)  16 pixels starting at byte offset off
+//   uint32_t apply1(uint32_t px, long long off)
+// VEC=false is the fallback for bases/strides that are not 16-byte aligned.
+// ---------------------------------------------------------------------------------------
+template <bool VEC, class F>
+__global__ __launch_bounds__(256) void pointwise_kernel(const uint8_t *__restrict__ in,
+                                                        uint8_t *__restrict__ out, long long N,
+                                                        long long in_stride, long long out_stride, F f) {
+    const int b = blockIdx.y;
+    const uint8_t *src = in + (long long)b * in_stride;
+    uint8_t *dst = out + (long long)b * out_stride;
+    f.begin(b);
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    if (VEC) {
+        const long long nchunks = N >> 4;
+        for (long long c = tid; c < nchunks; c += nthreads) {
+            u32x4 v = ld16(src + (c << 4));
+            st16(dst + (c << 4), f.apply16(v, c << 4));
+        }
+        for (long long t = (nchunks << 4) + tid; t < N; t += nthreads) dst[t] = (uint8_t)f.apply1(src[t], t);
+    } else {
+        for (long long t = tid; t < N; t += nthreads) dst[t] = (uint8_t)f.apply1(src[t], t);
+    }
+}
+
+template <class F>
+static int launch_pointwise(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride,
+                            long long out_stride, F f, bool extra_aligned, void *stream) {
+    if (!in || !out || N <= 0 || B <= 0) return IAK_E_ARG;
+    bool vec = aligned16(in) && aligned16(out) && (in_stride % 16 == 0) && (out_stride % 16 == 0) && extra_aligned;
+    long long items = vec ? ((N + 15) >> 4) : N;
+    dim3 grid(blocks_x(items, 256, B), B);
+    if (vec)
+        hipLaunchKernelGGL((pointwise_kernel<true, F>), grid, dim3(256), 0, as_stream(stream), in, out, N, in_stride,
+                           out_stride, f);
+    else
+        hipLaunchKernelGGL((pointwise_kernel<false, F>), grid, dim3(256), 0, as_stream(stream), in, out, N, in_stride,
+                           out_stride, f);
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- look-up through a 256-byte table held in LDS -------------------------------------
+struct LutTable {
+    uint8_t v[256];
+};
+
+__device__ __forceinline__ u32x4 lut16(const uint8_t *lut, u32x4 px) {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        uint32_t x = px[w];
+        o[w] = pack4(lut[x & 0xff], lut[(x >> 8) & 0xff], lut[(x >> 16) & 0xff], lut[x >> 24]);
+    }
+    return o;
+}
+
+struct MapFn {  // out = (uchar)map[in], map int32[256] per image in global memory
+    const int32_t *map;
+    long long map_stride;
+    __device__ void begin(int b) {
+        __shared__ uint8_t lut[256];
+        lut_ = lut;
+        if (threadIdx.x < 256) lut[threadIdx.x] = (uint8_t)map[(long long)b * map_stride + threadIdx.x];
+        __syncthreads();
+    }
+    __device__ __forceinline__ u32x4 apply16(u32x4 px, long long) const { return lut16(lut_, px); }
+    __device__ __forceinline__ uint32_t apply1(uint32_t px, long long) const { return lut_[px]; }
+    uint8_t *lut_;
+};
+
+struct ConstLutFn {  // same table for every image, passed by value
+    LutTable t;
+    __device__ void begin(int) {
+        __shared__ uint8_t lut[256];
+        lut_ = lut;
+        if (threadIdx.x < 256) lut[threadIdx.x] = t.v[threadIdx.x];
+        __syncthreads();
+    }
+    __device__ __forceinline__ u32x4 apply16(u32x4 px, long long) const { return lut16(lut_, px); }
+    __device__ __forceinline__ uint32_t apply1(uint32_t px, long long) const { return lut_[px]; }
+    uint8_t *lut_;
+};
+
+// ---- threshold: in > t ? 255 : 0 ---------------------------------------------------------
+__device__ __forceinline__ uint32_t thr4(uint32_t x, int t) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o |= ((int)byte_of(x, k) > t ? 0xffu : 0u) << (8 * k);
+    return o;
+}
+
+struct ThresholdFn {
+    int t;
+    const int32_t *per_image;  // nullptr: use t
+    __device__ void begin(int b) {
+        if (per_image) t = per_image[b];
+    }
+    __device__ __forceinline__ u32x4 apply16(u32x4 px, long long) const {
+        u32x4 o;
+#pragma unroll
+        for (int w = 0; w < 4; w++) o[w] = thr4(px[w], t);
+        return o;
+    }
+    __device__ __forceinline__ uint32_t apply1(uint32_t px, long long) const { return (int)px > t ? 255u : 0u; }
+};
+
+// ---- salt and pepper from the code plane (0 keep, 1 pepper, 2 salt) ----------------------
+__device__ __forceinline__ uint32_t sp4(uint32_t px, uint32_t code) {
+    // per byte: any code bit set -> drop the pixel; code bit 1 set -> 255
+    uint32_t hit = (code | (code >> 1)) & 0x01010101u;
+    uint32_t salt = (code >> 1) & 0x01010101u;
+    uint32_t hitmask = (hit << 8) - hit;
+    uint32_t saltmask = (salt << 8) - salt;
+    return (px & ~hitmask) | saltmask;
+}
+
+struct SaltPepperFn {
+    const uint8_t *sp;
+    __device__ void begin(int) {}
+    __device__ __forceinline__ u32x4 apply16(u32x4 px, long long off) const {
+        u32x4 c = ld16(sp + off);
+        u32x4 o;
+#pragma unroll
+        for (int w = 0; w < 4; w++) o[w] = sp4(px[w], c[w]);
+        return o;
+    }
+    __device__ __forceinline__ uint32_t apply1(uint32_t px, long long off) const {
+        uint32_t c = sp[off];
+        return c == 0 ? px : (c == 2 ? 255u : 0u);
+    }
+};
+
+// ---- Gaussian noise: out = (uchar)(in + table[rv]) ------------------------------------
+struct GaussFn {
+    const uint8_t *rv;
+    const uint16_t *table;
+    long long table_stride;
+    __device__ void begin(int b) {
+        __shared__ uint16_t tab[256];
+        tab_ = tab;
+        if (threadIdx.x < 256) tab[threadIdx.x] = table[(long long)b * table_stride + threadIdx.x];
+        __syncthreads();
+    }
+    __device__ __forceinline__ uint32_t one(uint32_t px, uint32_t r) const {
+        uint32_t e = tab_[r];
+        return (e & 0x100u) ? 0u : ((px + e) & 0xffu);
+    }
+    __device__ __forceinline__ u32x4 apply16(u32x4 px, long long off) const {
+        u32x4 r = ld16(rv + off);
+        u32x4 o;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+            o[w] = pack4(one(byte_of(px[w], 0), byte_of(r[w], 0)), one(byte_of(px[w], 1), byte_of(r[w], 1)),
+                         one(byte_of(px[w], 2), byte_of(r[w], 2)), one(byte_of(px[w], 3), byte_of(r[w], 3)));
+        return o;
+    }
+    __device__ __forceinline__ uint32_t apply1(uint32_t px, long long off) const { return one(px, rv[off]); }
+    uint16_t *tab_;
+};
+
+// ---------------------------------------------------------------------------------------
+// Grayscale (+ histogram).  Histogram privatisation: one 256x32 table of 32-bit counters
+// per workgroup in LDS (32 KiB), counter (bin, lane & 31) at word bin*32 + (lane & 31).
+// A lane only ever touches the LDS bank equal to its lane number mod 32, so an LDS
+// atomic wave-instruction has no bank conflict whatever the pixel values are -- a
+// constant image costs the same as a uniform-random one.  Lanes l and l+32 can meet on
+// one counter; they are served in different halves of the instruction.  The 32 columns
+// are summed at the end and each non-empty bin is merged into the image's global
+// histogram with one atomic per workgroup.
+// ---------------------------------------------------------------------------------------
+#define HIST_COLS 32
+
+__device__ __forceinline__ void hist_zero(uint32_t *sh) {
+    for (int i = threadIdx.x; i < 256 * HIST_COLS; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void hist_add4(uint32_t *sh, uint32_t w, int col) {
+    atomicAdd(&sh[(w & 0xff) * HIST_COLS + col], 1u);
+    atomicAdd(&sh[((w >> 8) & 0xff) * HIST_COLS + col], 1u);
+    atomicAdd(&sh[((w >> 16) & 0xff) * HIST_COLS + col], 1u);
+    atomicAdd(&sh[(w >> 24) * HIST_COLS + col], 1u);
+}
+
+// 256 lanes: lane v sums the 32 columns of bin v (rotated start: conflict-free) and merges.
+// Value 0 is never reported (imageAnalysis.cu:136).
+__device__ __forceinline__ void hist_flush(const uint32_t *sh, uint32_t *hist_image) {
+    __syncthreads();
+    int v = threadIdx.x;
+    if (v < 256) {
+        uint32_t s = 0;
+#pragma unroll 8
+        for (int i = 0; i < HIST_COLS; i++) s += sh[v * HIST_COLS + ((i + v) & (HIST_COLS - 1))];
+        if (v != 0 && s != 0) atomicAdd(&hist_image[v], s);
+    }
+}
+
+__device__ __forceinline__ uint32_t lum1(uint32_t r, uint32_t g, uint32_t b) {
+    // imageAnalysis.cu:22, double literals, left-to-right, no contraction
+    double y = (.21 * (double)r + .72 * (double)g) + .07 * (double)b;
+    return (uint32_t)(int)y;
+}
+__device__ __forceinline__ uint32_t avg1(uint32_t r, uint32_t g, uint32_t b) { return (r + g + b) / 3u; }
+
+template <int METHOD>
+__device__ __forceinline__ uint32_t gray4(uint32_t r, uint32_t g, uint32_t b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t y = METHOD == 0 ? lum1(byte_of(r, k), byte_of(g, k), byte_of(b, k))
+                                 : avg1(byte_of(r, k), byte_of(g, k), byte_of(b, k));
+        o |= (y & 0xffu) << (8 * k);
+    }
+    return o;
+}
+
+template <int METHOD, bool HIST, bool VEC>
+__global__ __launch_bounds__(256) void gray_kernel(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ gray,
+                                                   uint32_t *__restrict__ hist, long long N, long long rgb_stride,
+                                                   long long gray_stride) {
+    __shared__ uint32_t sh[HIST ? 256 * HIST_COLS : 1];
+    const int b = blockIdx.y;
+    const uint8_t *R = rgb + (long long)b * rgb_stride;
+    const uint8_t *G = R + N;
+    const uint8_t *Bp = G + N;
+    uint8_t *dst = gray + (long long)b * gray_stride;
+    const int col = threadIdx.x & (HIST_COLS - 1);
+    if (HIST) hist_zero(sh);
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    long long scalar_from = 0;
+    if (VEC) {
+        const long long nchunks = N >> 4;
+        for (long long c = tid; c < nchunks; c += nthreads) {
+            u32x4 r = ld16(R + (c << 4)), g = ld16(G + (c << 4)), bl = ld16(Bp + (c << 4));
+            u32x4 o;
+#pragma unroll
+            for (int w = 0; w < 4; w++) o[w] = gray4<METHOD>(r[w], g[w], bl[w]);
+            st16(dst + (c << 4), o);
+            if (HIST) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) hist_add4(sh, o[w], col);
+            }
+        }
+        scalar_from = nchunks << 4;
+    }
+    for (long long t = scalar_from + tid; t < N; t += nthreads) {
+        uint32_t y = METHOD == 0 ? lum1(R[t], G[t], Bp[t]) : avg1(R[t], G[t], Bp[t]);
+        dst[t] = (uint8_t)y;
+        if (HIST) atomicAdd(&sh[(y & 0xff) * HIST_COLS + col], 1u);
+    }
+    if (HIST) hist_flush(sh, hist + (long long)b * 256);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void hist_kernel(const uint8_t *__restrict__ img, uint32_t *__restrict__ hist,
+                                                   long long N, long long stride) {
+    __shared__ uint32_t sh[256 * HIST_COLS];
+    const int b = blockIdx.y;
+    const uint8_t *src = img + (long long)b * stride;
+    const int col = threadIdx.x & (HIST_COLS - 1);
+    hist_zero(sh);
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    long long scalar_from = 0;
+    if (VEC) {
+        const long long nchunks = N >> 4;
+        for (long long c = tid; c < nchunks; c += nthreads) {
+            u32x4 v = ld16(src + (c << 4));
+#pragma unroll
+            for (int w = 0; w < 4; w++) hist_add4(sh, v[w], col);
+        }
+        scalar_from = nchunks << 4;
+    }
+    for (long long t = scalar_from + tid; t < N; t += nthreads) atomicAdd(&sh[src[t] * HIST_COLS + col], 1u);
+    hist_flush(sh, hist + (long long)b * 256);
+}
+
+// A workgroup's 32 KiB table and its 256-atomic merge are amortised over the pixels it
+// streams: give each at least ~64K pixels, and keep the whole launch near 2-4K workgroups.
+static int hist_blocks_x(long long N, int B) {
+    long long max_by_work = (N + 65535) / 65536;
+    long long want = (2048 + B - 1) / B;
+    long long bx = want < max_by_work ? want : max_by_work;
+    return (int)(bx < 1 ? 1 : bx);
+}
+
+}  // namespace iak
+
+using namespace iak;
+
+extern "C" {
+
+int iak_gray_hist(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B, long long rgb_stride,
+                  long long gray_stride, int method, void *stream) {
+    if (!rgb || !gray || W <= 0 || H <= 0 || B <= 0) return IAK_E_ARG;
+    if (method != 0 && method != 1) return IAK_E_ARG;
+    const long long N = (long long)W * H;
+    if (rgb_stride < 3 * N || gray_stride < N) return IAK_E_ARG;
+    const bool vec = aligned16(rgb) && aligned16(gray) && rgb_stride % 16 == 0 && gray_stride % 16 == 0 && N % 16 == 0;
+    hipStream_t s = as_stream(stream);
+    dim3 block(256);
+    if (hist) {
+        IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
+        dim3 grid(hist_blocks_x(N, B), B);
+#define GH(M, V) hipLaunchKernelGGL((gray_kernel<M, true, V>), grid, block, 0, s, rgb, gray, hist, N, rgb_stride, gray_stride)
+        if (method == 0) { if (vec) GH(0, true); else GH(0, false); }
+        else { if (vec) GH(1, true); else GH(1, false); }
+#undef GH
+    } else {
+        dim3 grid(blocks_x(vec ? N / 16 : N, 256, B), B);
+#define GN(M, V) hipLaunchKernelGGL((gray_kernel<M, false, V>), grid, block, 0, s, rgb, gray, (uint32_t *)nullptr, N, rgb_stride, gray_stride)
+        if (method == 0) { if (vec) GN(0, true); else GN(0, false); }
+        else { if (vec) GN(1, true); else GN(1, false); }
+#undef GN
+    }
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
+int iak_gray(const uint8_t *rgb, uint8_t *gray, int W, int H, int B, long long rgb_stride, long long gray_stride,
+             int method, void *stream) {
+    return iak_gray_hist(rgb, gray, nullptr, W, H, B, rgb_stride, gray_stride, method, stream);
+}
+
+int iak_hist(const uint8_t *img, uint32_t *hist, long long N, int B, long long stride, void *stream) {
+    if (!img || !hist || N <= 0 || B <= 0 || stride < N) return IAK_E_ARG;
+    hipStream_t s = as_stream(stream);
+    IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
+    dim3 grid(hist_blocks_x(N, B), B);
+    if (aligned16(img) && stride % 16 == 0)
+        hipLaunchKernelGGL((hist_kernel<true>), grid, dim3(256), 0, s, img, hist, N, stride);
+    else
+        hipLaunchKernelGGL((hist_kernel<false>), grid, dim3(256), 0, s, img, hist, N, stride);
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
+int iak_apply_map(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride, long long out_stride,
+                  const int32_t *map, long long map_stride, void *stream) {
+    if (!map || (map_stride != 0 && map_stride < 256)) return IAK_E_ARG;
+    MapFn f{map, map_stride, nullptr};
+    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, true, stream);
+}
+
+int iak_quantize(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride, long long out_stride,
+                 const int *levels, int numLevels, void *stream) {
+    if (numLevels < 0 || (numLevels > 0 && !levels)) return IAK_E_ARG;
+    // imageAnalysis.cu:767-775 collapses to a table: the first level whose [min,max)
+    // holds the value decides, otherwise the value is kept.
+    ConstLutFn f;
+    for (int v = 0; v < 256; v++) {
+        uint8_t o = (uint8_t)v;
+        for (int i = 0; i < numLevels; i++)
+            if (v >= levels[i * 3] && v < levels[i * 3 + 1]) {
+                o = (uint8_t)levels[i * 3 + 2];
+                break;
+            }
+        f.t.v[v] = o;
+    }
+    f.lut_ = nullptr;
+    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, true, stream);
+}
+
+int iak_threshold(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride, long long out_stride,
+                  int threshold, void *stream) {
+    ThresholdFn f{threshold, nullptr};
+    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, true, stream);
+}
+
+int iak_threshold_per_image(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride,
+                            long long out_stride, const int32_t *thr, void *stream) {
+    if (!thr) return IAK_E_ARG;
+    ThresholdFn f{0, thr};
+    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, true, stream);
+}
+
+int iak_salt_pepper(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride, long long out_stride,
+                    const uint8_t *sp, void *stream) {
+    if (!sp) return IAK_E_ARG;
+    SaltPepperFn f{sp};
+    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, aligned16(sp), stream);
+}
+
+int iak_gauss_noise(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride, long long out_stride,
+                    const uint8_t *rv, const uint16_t *table, long long table_stride, void *stream) {
+    if (!rv || !table || (table_stride != 0 && table_stride < 256)) return IAK_E_ARG;
+    GaussFn f{rv, table, table_stride, nullptr};
+    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, aligned16(rv), stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+/*
+ * iak.h -- C ABI of the MI355X (gfx950) image-analysis kernel library, libiak.so.
+ *
+ * This is the boundary a host binds instead of the reference's CUDA wrappers in
+ * imageAnalysisLib/imageAnalysis.cu.  Every entry point is a launcher: it enqueues
+ * work on the given HIP stream (void* = hipStream_t, NULL = default stream) and
+ * returns without synchronising.  Unless stated otherwise an entry point allocates
+ * nothing and frees nothing; all image pointers are DEVICE pointers.
+ *
+ * Batches: an image batch is B images of W*H bytes (row-major, no row padding, as
+ * the reference's Image struct, imageAnalysis.h:19-23), image b starting at
+ * base + b*stride bytes.  RGB batches are planar R|G|B per image
+ * (imageAnalysis.h:11-17, test/test.cu:53-59).
+ *
+ * Return value: 0 on success; a positive value is a hipError_t; negative values
+ * are the IAK_E_* argument errors below.
+ *
+ * Float semantics follow the reference source text evaluated without
+ * multiply-add contraction; undefined float->uchar casts are defined as
+ * truncate-to-int then modulo 256.
+ */
+#ifndef IAK_H
+#define IAK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IAK_E_ARG (-1)         /* null pointer, non-positive size, bad enum */
+#define IAK_E_UNSUPPORTED (-2) /* well-formed but outside what the kernels implement */
+#define IAK_E_TOO_LARGE (-3)   /* exceeds a fixed capacity (kernel taps, scratch) */
+
+#define IAK_MAX_TAPS 625       /* kW*kH limit for kernels passed by value (25x25) */
+
+int iak_version(void);
+/* Static string for a return code of this library (never NULL). */
+const char *iak_error_string(int code);
+
+/* ---- memory / stream helpers, so a host never has to name hip* itself ----------
+ * Replace cudaMalloc/cudaFree/cudaMemcpy in imageAnalysis.cu:866-907. These DO
+ * allocate / free / block as their names say. */
+int iak_malloc(void **dev_ptr, size_t bytes);
+int iak_free(void *dev_ptr);
+int iak_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int iak_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int iak_memset(void *dst_dev, int value, size_t bytes, void *stream);
+int iak_stream_sync(void *stream);
+int iak_device_count(int *count);
+int iak_set_device(int device);
+
+/* ---- colour ----------------------------------------------------------------------
+ * Replaces convertRGBToGrayscale + kernels (imageAnalysis.cu:17-37,43-70).
+ * method 0: (uchar)((.21*R)+(.72*G)+(.07*B)) in double; 1: (R+G+B)/3.
+ * Any other method returns IAK_E_ARG (the reference prints and leaves the image unset). */
+int iak_gray(const uint8_t *rgb, uint8_t *gray, int W, int H, int B,
+             long long rgb_stride, long long gray_stride, int method, void *stream);
+/* Same pass, also producing the 256-bin histogram of every grayscale image
+ * (hist[b*256+v], fully overwritten).  Fuses convertRGBToGrayscale with
+ * calculateHistogram (imageAnalysis.cu:130-152): bin 0 is always 0. */
+int iak_gray_hist(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B,
+                  long long rgb_stride, long long gray_stride, int method, void *stream);
+
+/* ---- histogram / equalisation / look-up family -------------------------------------
+ * Replaces calculateHistogram + calcHistogram (imageAnalysis.cu:130-152): value 0 is
+ * never counted.  hist[B][256] is fully overwritten. */
+int iak_hist(const uint8_t *img, uint32_t *hist, long long N, int B, long long stride, void *stream);
+/* Replaces equalizeHistogram (imageAnalysis.cu:155-176), on the device, one image per
+ * lane: the float32 pdf/cdf is accumulated sequentially in bin order. */
+int iak_eq_map(const uint32_t *hist, int32_t *map, int numPixels, int B, void *stream);
+/* Replaces equalizeImageWithHist + equalizeImage (imageAnalysis.cu:178-201):
+ * out = (uchar)map[in].  map is a DEVICE array [B][256]; map_stride is in elements
+ * (256 for one map per image, 0 to share one map). */
+int iak_apply_map(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride,
+                  long long out_stride, const int32_t *map, long long map_stride, void *stream);
+/* Replaces imageQuantization (imageAnalysis.cu:764-778,814-828).  levels is a HOST array
+ * of numLevels x {min,max,val}; numLevels == 0 copies the image. */
+int iak_quantize(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride,
+                 long long out_stride, const int *levels, int numLevels, void *stream);
+/* Replaces thresholdImage (imageAnalysis.cu:207-226): in > threshold ? 255 : 0. */
+int iak_threshold(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride,
+                  long long out_stride, int threshold, void *stream);
+/* Same with one threshold per image, read from the DEVICE array thr[B]. */
+int iak_threshold_per_image(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride,
+                            long long out_stride, const int32_t *thr, void *stream);
+/* The host loop of otsuThresholdImage (imageAnalysis.cu:255-277) on the device, from
+ * histograms with bin 0 empty (as iak_hist gives them): thr[b] for every image. */
+int iak_otsu_threshold(const uint32_t *hist, int32_t *thr, int numPixels, int B, void *stream);
+/* calculateMeanAndStdDev (imageAnalysis.cu:106-128) from histograms with bin 0 empty:
+ * mean_std[b*2] = mean, mean_std[b*2+1] = standard deviation.  The pixel sum is
+ * exact (the reference's float tree sum has no defined order). */
+int iak_mean_std(const uint32_t *hist, float *mean_std, int numPixels, int B, void *stream);
+
+/* ---- random numbers --------------------------------------------------------------------
+ * Replaces setupRandomness + setup_kernel (imageAnalysis.cu:709-715,740-746).
+ * curand_init(seed, tid, 0) followed by two curand() draws, for tid in [0,N): the only
+ * two outputs the noise kernels ever consume, because they never store their state
+ * back (imageAnalysis.cu:723,836).  x0/x1: DEVICE arrays of N words. */
+int iak_rng_planes(uint32_t *x0, uint32_t *x1, long long N, unsigned long long seed, void *stream);
+/* rv[t] = (int)(uniform(x0[t]) * 255.999999), the draw of imageAnalysis.cu:837. */
+int iak_rv_plane(const uint32_t *x0, uint8_t *rv, long long N, void *stream);
+/* sp[t] = 0 keep, 1 pepper (0), 2 salt (255) for a given level (imageAnalysis.cu:724-731). */
+int iak_sp_plane(const uint32_t *x0, const uint32_t *x1, uint8_t *sp, long long N, int level, void *stream);
+
+/* ---- noise ---------------------------------------------------------------------------
+ * Replaces saltAndPepperNoise + generateSaltAndPepper (imageAnalysis.cu:717-737,753-762)
+ * given the plane of iak_sp_plane (shared by all images of the batch, as the
+ * reference's per-tid states are). */
+int iak_salt_pepper(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride,
+                    long long out_stride, const uint8_t *sp, void *stream);
+/* The per-image amplitude table of addGaussianNoiseToImage (imageAnalysis.cu:841):
+ * table[b*256+rv] = round(255*exp(-(rv-mean)^2/(2*std^2))) in the low byte, 0x100 set
+ * where that value is NaN.  If mean == -1 or stddev == -1 both come from image b's
+ * histogram (imageAnalysis.cu:858-860); hist may be NULL otherwise. */
+int iak_gauss_table(const uint32_t *hist, int numPixels, int B, float mean, float stddev,
+                    uint16_t *table, void *stream);
+/* Replaces addGaussianNoise's kernel (imageAnalysis.cu:831-847): out = (uchar)(in + table[rv[t]]).
+ * table_stride in elements (256 per image, 0 shared). */
+int iak_gauss_noise(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride,
+                    long long out_stride, const uint8_t *rv, const uint16_t *table,
+                    long long table_stride, void *stream);
+
+/* ---- stencils --------------------------------------------------------------------------
+ * All share the reference's border rule (imageAnalysis.cu:514): with a=(kH-1)/2,
+ * s=(kW-1)/2 the output is 0 where row<a || row>H-a || col<s || col>W-s; taps are read
+ * at flat index i*W+j (column W is the next row's first pixel) and read 0 at or past
+ * W*H.  kernel / weights / se are HOST arrays of kW*kH values (<= IAK_MAX_TAPS). */
+#define IAK_LINEAR_CLAMP 0   /* linearFilter  (imageAnalysis.cu:507-547) */
+#define IAK_LINEAR_AVERAGE 1 /* averageFilter (imageAnalysis.cu:469-505) */
+int iak_linear(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+               long long out_stride, const float *kernel, int kW, int kH, int mode, void *stream);
+/* Replaces medianFilter (imageAnalysis.cu:641-706) without its global scratch: each pixel
+ * keeps its window privately.  Even sizes and negative weights return IAK_E_UNSUPPORTED. */
+int iak_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+               long long out_stride, const int *weights, int kW, int kH, void *stream);
+/* Replaces sobelFilter (imageAnalysis.cu:549-590): both clamped 3x3 responses and the
+ * magnitude in one pass; setupEdgeDetection's device masks are not needed. */
+int iak_sobel(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+              long long out_stride, void *stream);
+/* Replaces compassFilter (imageAnalysis.cu:592-639). */
+int iak_compass(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+                long long out_stride, void *stream);
+/* Replaces imageDilation (imageAnalysis.cu:381-419) as a gather: out = 255 where any
+ * interior foreground pixel's window covers the pixel through a non-zero element. */
+int iak_dilate(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+               long long out_stride, const int *se, int kW, int kH, void *stream);
+/* Replaces imageErosion (imageAnalysis.cu:421-467). */
+int iak_erode(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+              long long out_stride, const int *se, int kW, int kH, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,140 @@
+/*
+ * ia_oracle.h -- CPU restatement of imageAnalysisLib's per-pixel path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing that ships (the HIP library, the C++ API
+ * layer, the pipeline driver) may link or call this file; only tests/, the
+ * smoke check and the cpu_baseline leg of bench.py do, and only as the checker.
+ *
+ * PARITY UNPINNED: the reference holds no golden vectors, known-answer tests
+ * or fixtures, and it cannot be built here (CUDA, cuRAND, Thrust, OpenCV,
+ * jsoncpp are absent).  Every function below restates the reference source
+ * text (cited per function as imageAnalysis.cu:line) as one scalar "logical
+ * thread per pixel" loop.  Where the reference is racy, reads out of bounds or
+ * relies on undefined casts, the resolution used here is stated at the
+ * function.  The known-answer vectors under tests/golden/ were produced by
+ * this file and hand-checked against the source text.
+ *
+ * Float rules: compile with -ffp-contract=off; every float expression keeps
+ * the reference's operand types and evaluation order.
+ */
+#ifndef IA_ORACLE_H
+#define IA_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- colour ------------------------------------------------------------ */
+/* imageAnalysis.cu:17-37,43-70.  rgb is planar R|G|B, 3*W*H bytes.
+ * method 0: (uchar)((.21*R)+(.72*G)+(.07*B)) in double; 1: (R+G+B)/3.
+ * Returns 0, or -1 for an unknown method (output untouched). */
+int iao_gray(const uint8_t *rgb, uint8_t *gray, int W, int H, int method);
+
+/* ---- histogram / equalisation / LUT family ------------------------------ */
+/* imageAnalysis.cu:130-152.  256 bins, value 0 is never counted. */
+void iao_hist(const uint8_t *img, long N, int *hist);
+/* imageAnalysis.cu:155-176.  Sequential float32 pdf/cdf. */
+void iao_eq_map(const int *hist, int *map, int numPixels);
+/* imageAnalysis.cu:178-186.  out = (uchar)map[in]. */
+void iao_apply_map(const uint8_t *in, uint8_t *out, long N, const int *map);
+/* imageAnalysis.cu:764-778,814-828.  levels = numLevels x {min,max,val}.
+ * numLevels == 0 leaves the reference's output unwritten; here: identity. */
+void iao_quantize(const uint8_t *in, uint8_t *out, long N, const int *levels, int numLevels);
+/* imageAnalysis.cu:207-226. */
+void iao_threshold(const uint8_t *in, uint8_t *out, long N, int threshold);
+/* imageAnalysis.cu:237-279.  Returns the threshold; out may be NULL. */
+int iao_otsu(const uint8_t *in, uint8_t *out, int W, int H);
+/* imageAnalysis.cu:106-128.  Thrust's float tree sums are order-unspecified;
+ * here: exact integer pixel sum, mean=(float)sum/(float)N,
+ * var=(float)(sum_v cnt[v]*((double)((float)v-mean))^2)/(float)(N-1). */
+void iao_mean_std(const uint8_t *in, long N, float *mean, float *stddev);
+/* Same statistics from a full 256-bin histogram (bin 0 included). */
+void iao_mean_std_from_hist(const long long *cnt, long N, float *mean, float *stddev);
+
+/* ---- random numbers ------------------------------------------------------ */
+/* XORWOW as initialised by curand_init(seed, subsequence=tid, offset=0)
+ * (imageAnalysis.cu:709-715): first two 32-bit outputs of subsequence tid.
+ * The states are never written back (imageAnalysis.cu:723,836), so these two
+ * words are all the noise kernels ever see. */
+void iao_xorwow_pair(unsigned long long seed, unsigned int tid, uint32_t *x0, uint32_t *x1);
+void iao_xorwow_planes(unsigned long long seed, long N, uint32_t *x0, uint32_t *x1);
+/* Plain generator access for self-checks: state init + n sequential outputs. */
+void iao_xorwow_stream(unsigned long long seed, unsigned int subsequence, int n, uint32_t *out);
+/* The 160x160 GF(2) matrix of 2^log2steps generator steps, as 160 rows of 5
+ * words (row i*32+j = image of bit j of state word i). */
+void iao_xorwow_jump_matrix(int log2steps, uint32_t *m800);
+/* curand_uniform's mapping of a 32-bit output to (0,1]. */
+float iao_uniform(uint32_t x);
+
+/* imageAnalysis.cu:717-737,753-762. */
+void iao_salt_pepper(const uint8_t *in, uint8_t *out, long N,
+                     const uint32_t *x0, const uint32_t *x1, int level);
+/* imageAnalysis.cu:831-863.  mean == -1 or stddev == -1 => both from the image.
+ * The 256-entry amplitude table is exposed so its construction can be checked
+ * on its own. use_libm != 0 swaps the portable exp for libm's expf. */
+void iao_gauss_table(float mean, float variance, uint8_t *table256, int use_libm);
+void iao_gauss_noise(const uint8_t *in, uint8_t *out, long N,
+                     const uint32_t *x0, float mean, float stddev);
+
+/* ---- stencils ---------------------------------------------------------------
+ * Border rule shared by all (imageAnalysis.cu:389,429,476,514,649): with
+ * a=(kH-1)/2, s=(kW-1)/2 a pixel is border (output 0) iff
+ * row<a || row>H-a || col<s || col>W-s.  Taps are read at flat index i*W+j, so
+ * column W wraps to the next row; flat indices >= W*H (the reference reads past
+ * its allocation there) read as 0. */
+/* imageAnalysis.cu:507-547. */
+void iao_linear(const uint8_t *in, uint8_t *out, int W, int H, const float *kernel, int kW, int kH);
+/* imageAnalysis.cu:469-505. */
+void iao_average(const uint8_t *in, uint8_t *out, int W, int H, const float *kernel, int kW, int kH);
+/* imageAnalysis.cu:641-706.  Race-free private window, weights replicate, result
+ * sorted[kernSum/2].  Returns -1 (nothing written) for even sizes or negative
+ * weights, where the reference reads uninitialised scratch. */
+int iao_median(const uint8_t *in, uint8_t *out, int W, int H, const int *weights, int kW, int kH);
+/* imageAnalysis.cu:549-590. */
+void iao_sobel(const uint8_t *in, uint8_t *out, int W, int H);
+/* imageAnalysis.cu:592-639.  k restarts per mask; sum carries across masks. */
+void iao_compass(const uint8_t *in, uint8_t *out, int W, int H);
+/* imageAnalysis.cu:381-419.  Racy scatter; resolution "255 wins". */
+void iao_dilate(const uint8_t *in, uint8_t *out, int W, int H, const int *se, int kW, int kH);
+/* Same kernel executed as one sequential loop in ascending tid (another legal
+ * outcome of the race); used for the property seq <= maxwins. */
+void iao_dilate_seq(const uint8_t *in, uint8_t *out, int W, int H, const int *se, int kW, int kH);
+/* imageAnalysis.cu:421-467. */
+void iao_erode(const uint8_t *in, uint8_t *out, int W, int H, const int *se, int kW, int kH);
+
+/* ---- segmentation / features (callers of the path) ------------------------- */
+/* imageAnalysis.cu:281-379 with explicit initial centroids (the reference draws
+ * them from unseeded rand()).  Class sums/counts start at zero (the reference
+ * never zeroes them).  Returns iterations run. */
+int iao_kmeans2(const uint8_t *in, uint8_t *out, long N, int c0, int c1);
+/* imageMachineLearning.cu:341-422: mean,std,area,perimeter,mode,rangeMin,rangeMax */
+void iao_features(const uint8_t *in, int W, int H, float *feat7);
+
+/* ---- whole pipelines, for the CPU baseline and executor parity ------------- */
+enum {
+    IAO_OP_EQUALIZE = 1, IAO_OP_GAUSS = 2, IAO_OP_SALT_PEPPER = 3, IAO_OP_LINEAR = 4,
+    IAO_OP_AVERAGE = 5, IAO_OP_MEDIAN = 6, IAO_OP_SOBEL = 7, IAO_OP_COMPASS = 8,
+    IAO_OP_DILATE = 9, IAO_OP_ERODE = 10, IAO_OP_THRESHOLD = 11, IAO_OP_OTSU = 12,
+    IAO_OP_QUANTIZE = 13
+};
+typedef struct {
+    int type;
+    int kW, kH;           /* stencils */
+    const float *fkernel; /* linear / average */
+    const int *ikernel;   /* median weights, structuring element, quantisation levels */
+    int iparam;           /* S&P level, threshold, numLevels */
+    float mean, stddev;   /* gaussian */
+} iao_op;
+/* rgb: B planar images; out: B gray images; hist_sum: 256 x int64 dataset
+ * histogram of the grayscale images (bin 0 empty, as iao_hist).  x0/x1 planes
+ * may be NULL when no noise op is present.  threads<=1: serial. */
+void iao_pipeline(const uint8_t *rgb, uint8_t *out, int W, int H, int B,
+                  const iao_op *ops, int nops, const uint32_t *x0, const uint32_t *x1,
+                  long long *hist_sum, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

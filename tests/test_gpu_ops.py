@@ -1,0 +1,316 @@
+"""Parity of every HIP entry point against the CPU oracle, through the C ABI, bit for bit.
+All ops here are integer/byte results; float stages (grayscale, linear, Gaussian table,
+Sobel) are also required bit-exact -- the +-1 LSB allowance of the float filters is not
+used."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(64, 48), (768, 72), (37, 23), (16, 5), (48, 3), (5, 7), (1, 1), (130, 9)]
+KINDS = ["U", "C", "K"]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from imageanalysis_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def batch(kind, W, H, B=3):
+    return synth.gray_batch(kind, W, H, B)
+
+
+def each(fn_gpu, fn_ref, imgs):
+    got = host(fn_gpu(dev(imgs)))
+    for b in range(imgs.shape[0]):
+        want = fn_ref(imgs[b])
+        assert got[b].shape == want.shape
+        if not np.array_equal(got[b], want):
+            bad = np.argwhere(got[b] != want)
+            raise AssertionError(f"image {b}: {len(bad)} mismatches, first at {bad[0]}: got "
+                                 f"{got[b][tuple(bad[0])]} want {want[tuple(bad[0])]}")
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("method", [0, 1])
+def test_gray(ops, W, H, kind, method):
+    rgb = synth.rgb_batch(kind, W, H, 3)
+    got = host(ops.convertRGBToGrayscale(dev(rgb), method))
+    for b in range(3):
+        assert np.array_equal(got[b], O.gray(rgb[b], method))
+
+
+def test_gray_all_triples_sample(ops):
+    # every (R,G,B) with R,G on a stride-3 lattice and all B: covers the exact-multiple-of-100
+    # cases where the double sum lands just below an integer (white -> 254)
+    r, g, b = np.meshgrid(np.arange(0, 256, 3), np.arange(0, 256, 3), np.arange(256), indexing="ij")
+    n = r.size
+    W = 256
+    H = (n + W - 1) // W
+    rgb = np.zeros((3, H * W), np.uint8)
+    rgb[0, :n], rgb[1, :n], rgb[2, :n] = r.ravel(), g.ravel(), b.ravel()
+    rgb = rgb.reshape(3, H, W)
+    got = host(ops.convertRGBToGrayscale(dev(rgb), 0))
+    assert np.array_equal(got, O.gray(rgb, 0))
+    assert int(host(ops.convertRGBToGrayscale(dev(np.full((3, 1, 1), 255, np.uint8)), 0))[0, 0]) == 254
+
+
+def test_gray_bad_method(ops):
+    from imageanalysis_amd.lib import IakError
+    with pytest.raises(IakError):
+        ops.convertRGBToGrayscale(dev(np.zeros((3, 4, 4), np.uint8)), 2)
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_gray_hist_fused(ops, W, H, kind):
+    rgb = synth.rgb_batch(kind, W, H, 3)
+    gray, hist = ops.convertRGBToGrayscale(dev(rgb), 0, with_hist=True)
+    gray, hist = host(gray), host(hist)
+    for b in range(3):
+        want = O.gray(rgb[b], 0)
+        assert np.array_equal(gray[b], want)
+        assert np.array_equal(hist[b], O.hist(want))
+
+
+@pytest.mark.parametrize("W,H", SIZES + [(768, 568)])
+@pytest.mark.parametrize("kind", KINDS)
+def test_histogram(ops, W, H, kind):
+    imgs = batch(kind, W, H, 2)
+    got = host(ops.calculateHistogram(dev(imgs)))
+    for b in range(2):
+        assert np.array_equal(got[b], O.hist(imgs[b]))
+    assert (got[:, 0] == 0).all()
+
+
+def test_histogram_all_zero_and_all_255(ops):
+    z = np.zeros((1, 48, 64), np.uint8)
+    assert host(ops.calculateHistogram(dev(z))).sum() == 0
+    f = np.full((1, 48, 64), 255, np.uint8)
+    h = host(ops.calculateHistogram(dev(f)))[0]
+    assert h[255] == 48 * 64 and h.sum() == 48 * 64
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_equalization(ops, W, H, kind):
+    imgs = batch(kind, W, H)
+    h = ops.calculateHistogram(dev(imgs))
+    m = host(ops.equalizeHistogram(h, W * H))
+    for b in range(imgs.shape[0]):
+        assert np.array_equal(m[b], O.eq_map(O.hist(imgs[b]), W * H))
+    each(ops.histogramEqualization, O.equalize, imgs)
+
+
+def test_eq_map_kat(ops):
+    h = np.zeros((1, 256), np.int32)
+    h[0, 10], h[0, 20], h[0, 200] = 4, 4, 8
+    m = host(ops.equalizeHistogram(dev(h), 16))[0]
+    assert m[9] == 0 and (m[10:20] == 63).all() and (m[20:200] == 127).all() and (m[200:] == 255).all()
+
+
+LEVEL_SETS = [
+    [[10, 20, 15], [30, 250, 77]],                                   # input.json:24-36
+    [[0, 50, 25], [50, 100, 75], [100, 150, 125], [150, 200, 175], [200, 250, 225], [40, 256, 300]],
+    [],
+    [[0, 256, 7]],
+]
+
+
+@pytest.mark.parametrize("levels", LEVEL_SETS)
+@pytest.mark.parametrize("W,H", [(64, 48), (37, 23)])
+def test_quantization(ops, W, H, levels):
+    imgs = batch("U", W, H)
+    each(lambda x: ops.imageQuantization(x, levels), lambda x: O.quantize(x, levels), imgs)
+
+
+@pytest.mark.parametrize("t", [-1, 0, 40, 127, 254, 255, 300])
+@pytest.mark.parametrize("W,H", [(64, 48), (37, 23)])
+def test_threshold(ops, W, H, t):
+    imgs = batch("U", W, H)
+    each(lambda x: ops.thresholdImage(x, t), lambda x: O.threshold(x, t), imgs)
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_otsu(ops, W, H, kind):
+    imgs = batch(kind, W, H)
+    out, thr = ops.otsuThresholdImage(dev(imgs), return_threshold=True)
+    out, thr = host(out), host(thr)
+    for b in range(imgs.shape[0]):
+        want, wthr = O.otsu(imgs[b])
+        assert thr[b] == wthr
+        assert np.array_equal(out[b], want)
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_mean_std(ops, W, H, kind):
+    imgs = batch(kind, W, H)
+    ms = host(ops.calculateMeanAndStdDev(dev(imgs)))
+    for b in range(imgs.shape[0]):
+        m, s = O.mean_std(imgs[b])
+        assert ms[b, 0].tobytes() == m.tobytes()
+        assert ms[b, 1].tobytes() == s.tobytes() or (np.isnan(ms[b, 1]) and np.isnan(s))
+
+
+def test_rng_planes(ops):
+    n = 70000  # crosses bit 16 of the subsequence number
+    rng = ops.Randomness(n)
+    x0, x1 = O.xorwow_planes(n)
+    assert np.array_equal(host(rng.x0).view(np.uint32), x0)
+    assert np.array_equal(host(rng.x1).view(np.uint32), x1)
+
+
+def test_rng_planes_high_subsequence(ops):
+    # spot-check subsequence numbers up to 2^24 (4096x4096 images) without the full oracle plane
+    n = 1 << 24
+    rng = ops.Randomness(n)
+    x0 = host(rng.x0).view(np.uint32)
+    x1 = host(rng.x1).view(np.uint32)
+    for tid in [0, 1, 65535, 65536, 436223, 1 << 20, (1 << 24) - 1, 0xABCDEF]:
+        s = O.xorwow_stream(1234, tid, 2)
+        assert x0[tid] == s[0] and x1[tid] == s[1]
+
+
+@pytest.mark.parametrize("W,H", [(64, 48), (37, 23), (768, 72)])
+@pytest.mark.parametrize("level", [50, 0, 1, 7, 255])
+def test_salt_pepper(ops, W, H, level):
+    imgs = batch("C", W, H)
+    rng = ops.Randomness(W * H)
+    x0, x1 = O.xorwow_planes(W * H)
+    each(lambda x: ops.saltAndPepperNoise(x, rng, level), lambda x: O.salt_pepper(x, x0, x1, level), imgs)
+
+
+@pytest.mark.parametrize("W,H", [(64, 48), (37, 23), (768, 72)])
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("mean,std", [(-1.0, -1.0), (128.0, 20.0), (-1.0, 5.0), (100.0, 0.0)])
+def test_gauss_noise(ops, W, H, kind, mean, std):
+    imgs = batch(kind, W, H)
+    rng = ops.Randomness(W * H)
+    x0, _ = O.xorwow_planes(W * H)
+    each(lambda x: ops.addGaussianNoise(x, rng, mean, std), lambda x: O.gauss_noise(x, x0, mean, std), imgs)
+
+
+KERNELS3 = {
+    "input.json": [1, 1, 1, 10, 1, 1, 1, 1, 1],
+    "linear-filter.json": [-1, 0, -1, -2, 0, -2, -1, 0, -1],
+    "box9": [1.0 / 9] * 9,
+    "gauss16": [1 / 16, 2 / 16, 1 / 16, 2 / 16, 4 / 16, 2 / 16, 1 / 16, 2 / 16, 1 / 16],
+    "sharpen": [0, -1, 0, -1, 5, -1, 0, -1, 0],
+    "odd": [0.3, -0.7, 1.9, 0.01, 2.5, -1.3, 0.77, 0.2, -0.45],
+}
+
+
+@pytest.mark.parametrize("name", list(KERNELS3))
+@pytest.mark.parametrize("W,H", SIZES)
+@pytest.mark.parametrize("avg", [False, True])
+def test_linear3(ops, name, W, H, avg):
+    k = KERNELS3[name]
+    imgs = batch("U", W, H)
+    if avg:
+        each(lambda x: ops.averageFilter(x, k, 3, 3), lambda x: O.average(x, k, 3, 3), imgs)
+    else:
+        each(lambda x: ops.linearFilter(x, k, 3, 3), lambda x: O.linear(x, k, 3, 3), imgs)
+
+
+@pytest.mark.parametrize("kW,kH", [(5, 5), (11, 11), (3, 5), (7, 1), (1, 1), (2, 2), (4, 3)])
+@pytest.mark.parametrize("W,H", [(64, 48), (37, 23), (16, 5)])
+def test_linear_generic(ops, kW, kH, W, H):
+    rs = np.random.default_rng(kW * 100 + kH)
+    k = (rs.random(kW * kH).astype(np.float32) / (kW * kH) * 1.7)
+    imgs = batch("C", W, H, 2)
+    each(lambda x: ops.linearFilter(x, k, kW, kH), lambda x: O.linear(x, k, kW, kH), imgs)
+    each(lambda x: ops.averageFilter(x, k * 9, kW, kH), lambda x: O.average(x, k * 9, kW, kH), imgs)
+
+
+@pytest.mark.parametrize("W,H", SIZES + [(768, 568)])
+@pytest.mark.parametrize("kind", KINDS)
+def test_median3(ops, W, H, kind):
+    imgs = batch(kind, W, H, 2)
+    w = [1] * 9
+    each(lambda x: ops.medianFilter(x, w, 3, 3), lambda x: O.median(x, w, 3, 3), imgs)
+
+
+@pytest.mark.parametrize("kW,kH,weights", [
+    (5, 5, [1] * 25), (7, 7, [1] * 49), (3, 3, [1, 2, 1, 2, 3, 2, 1, 2, 1]), (3, 1, [1, 1, 1]),
+    (1, 1, [1]), (3, 3, [0, 1, 0, 1, 1, 1, 0, 1, 0]), (5, 3, list(range(15)))])
+@pytest.mark.parametrize("W,H", [(64, 48), (37, 23)])
+def test_median_generic(ops, kW, kH, weights, W, H):
+    imgs = batch("U", W, H, 2)
+    each(lambda x: ops.medianFilter(x, weights, kW, kH), lambda x: O.median(x, weights, kW, kH), imgs)
+
+
+def test_median_rejects(ops):
+    from imageanalysis_amd.lib import IakError
+    x = dev(batch("U", 16, 8, 1))
+    with pytest.raises(IakError):
+        ops.medianFilter(x, [1] * 4, 2, 2)
+    with pytest.raises(IakError):
+        ops.medianFilter(x, [1, -1, 1, 1, 1, 1, 1, 1, 1], 3, 3)
+    assert O.median(batch("U", 16, 8, 1)[0], [1] * 4, 2, 2) is None
+
+
+@pytest.mark.parametrize("W,H", SIZES + [(768, 568)])
+@pytest.mark.parametrize("kind", KINDS)
+def test_sobel_compass(ops, W, H, kind):
+    imgs = batch(kind, W, H, 2)
+    each(ops.sobelFilter, O.sobel, imgs)
+    each(ops.compassFilter, O.compass, imgs)
+
+
+SES = {
+    "ones3": (3, 3, [1] * 9),
+    "cross3": (3, 3, [0, 1, 0, 1, 1, 1, 0, 1, 0]),
+    "asym3": (3, 3, [1, 0, 0, 0, 0, 1, 0, 7, 0]),
+    "zero3": (3, 3, [0] * 9),
+    "ones5": (5, 5, [1] * 25),
+    "bar": (5, 1, [1, 0, 1, 1, 0]),
+    "col": (1, 3, [1, 1, 1]),
+    "even": (2, 2, [1, 1, 1, 1]),
+}
+
+
+@pytest.mark.parametrize("se", list(SES))
+@pytest.mark.parametrize("W,H", SIZES)
+def test_morphology(ops, se, W, H):
+    kW, kH, v = SES[se]
+    rs = np.random.default_rng(5)
+    imgs = batch("U", W, H, 2)
+    imgs[rs.random(imgs.shape) < 0.6] = 0  # sparse foreground so erosion/dilation are non-trivial
+    each(lambda x: ops.imageErosion(x, v, kW, kH), lambda x: O.erode(x, v, kW, kH), imgs)
+    each(lambda x: ops.imageDilation(x, v, kW, kH), lambda x: O.dilate(x, v, kW, kH), imgs)
+    dense = batch("C", W, H, 1)
+    each(lambda x: ops.imageErosion(x, v, kW, kH), lambda x: O.erode(x, v, kW, kH), dense)
+    each(lambda x: ops.imageDilation(x, v, kW, kH), lambda x: O.dilate(x, v, kW, kH), dense)
+
+
+def test_strided_batch_views(ops):
+    # images embedded in a larger allocation: stride > W*H, 16-byte aligned and not
+    W, H = 64, 48
+    for pad in (16, 5):
+        buf = torch.zeros((3, H * W + pad), dtype=torch.uint8, device="cuda")
+        imgs = batch("U", W, H, 3)
+        view = buf[:, :H * W].view(3, H, W)
+        view.copy_(dev(imgs))
+        got = host(ops.medianFilter(view, [1] * 9, 3, 3))
+        for b in range(3):
+            assert np.array_equal(got[b], O.median(imgs[b], [1] * 9, 3, 3))
+        got = host(ops.histogramEqualization(view))
+        for b in range(3):
+            assert np.array_equal(got[b], O.equalize(imgs[b]))
