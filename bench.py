@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpixels/s of the full filter pipeline (grayscale -> histogram ->
+equalise -> Gaussian noise -> salt-and-pepper -> 3x3 linear -> 3x3 median -> Sobel) on a
+device-resident batch of synthetic 768x568 cell-like images, through the C ABI's batched
+executor.  One process per GPU; images shard image-wise (every rank owns a full batch,
+weak scaling); the only collective is one all-reduce of the 256-bin dataset histogram per
+step.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from imageanalysis_amd import lib as iak_lib  # noqa: E402
+from imageanalysis_amd.pipeline import Pipeline  # noqa: E402
+
+W, H = 768, 568
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+GAUSS16 = [1 / 16, 2 / 16, 1 / 16, 2 / 16, 4 / 16, 2 / 16, 1 / 16, 2 / 16, 1 / 16]
+OP_EQUALIZE, OP_GAUSS, OP_SP, OP_LINEAR, OP_MEDIAN, OP_SOBEL = 1, 2, 3, 4, 6, 7
+P_A = [
+    {"type": OP_EQUALIZE},
+    {"type": OP_GAUSS, "mean": -1.0, "stddev": -1.0},
+    {"type": OP_SP, "iparam": 50},
+    {"type": OP_LINEAR, "kW": 3, "kH": 3, "fkernel": GAUSS16},
+    {"type": OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": [1] * 9},
+    {"type": OP_SOBEL},
+]
+P_A_BYTES_PER_PX = 19  # gray 4, hist 1, equalise 2, gaussian 3, salt-pepper 3, linear 2, median 2, sobel 2
+
+
+def make_cell_batch(B, device, seed):
+    """Cell-like synthetic images generated on the device: bright background N(200,8), 12
+    dark elliptical blobs N(90,20), the three channels equal up to +-3 jitter."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty((B, 3, H, W), dtype=torch.uint8, device=device)
+    yy = torch.arange(H, device=device, dtype=torch.float32).view(1, H, 1)
+    xx = torch.arange(W, device=device, dtype=torch.float32).view(1, 1, W)
+    step = 50
+    for s in range(0, B, step):
+        n = min(step, B - s)
+        base = 200.0 + 8.0 * torch.randn((n, H, W), generator=g, device=device)
+        for _ in range(12):
+            cy = torch.rand((n, 1, 1), generator=g, device=device) * H
+            cx = torch.rand((n, 1, 1), generator=g, device=device) * W
+            ry = torch.rand((n, 1, 1), generator=g, device=device) * (H / 8 - H / 30) + H / 30 + 1
+            rx = torch.rand((n, 1, 1), generator=g, device=device) * (W / 8 - W / 30) + W / 30 + 1
+            inside = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+            blob = 90.0 + 20.0 * torch.randn((n, H, W), generator=g, device=device)
+            base = torch.where(inside, blob, base)
+        base = torch.round(base)
+        for c in range(3):
+            jit = torch.randint(-3, 4, (n, H, W), generator=g, device=device).to(torch.float32)
+            out[s:s + n, c] = torch.clamp(base + jit, 0, 255).to(torch.uint8)
+    return out
+
+
+def cpu_baseline(rgb_dev, n_threads):
+    """The CPU oracle (a port of the reference's CUDA kernels, oracle/ia_oracle.c) on a
+    bounded sample of the same batch, on this machine's host cores."""
+    import oracle_lib as O
+    O.lib()
+    x0, x1 = O.xorwow_planes(W * H)
+    probe = rgb_dev[:n_threads].cpu().numpy()
+    t0 = time.perf_counter()
+    O.pipeline(probe, P_A, x0, x1, threads=n_threads)
+    dt = time.perf_counter() - t0
+    per_image_cpu_s = dt * n_threads / probe.shape[0]
+    # about 15 s of CPU work in total, at least one image per thread, at most what we hold
+    n = int(max(n_threads, min(rgb_dev.shape[0], 15.0 / max(per_image_cpu_s, 1e-6))))
+    n = max(n_threads, (n // n_threads) * n_threads)
+    n = min(n, rgb_dev.shape[0])
+    sample = rgb_dev[:n].cpu().numpy()
+    t0 = time.perf_counter()
+    out, _ = O.pipeline(sample, P_A, x0, x1, threads=n_threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(n * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "cores": n_threads, "kind": "port",
+        "sample": f"{n} of the batch's 768x568 images, full pipeline, OpenMP over images, {dt:.2f} s wall",
+    }, out, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=500, help="images per GPU per step")
+    ap.add_argument("--stagewise", action="store_true", help="one pass per operation (no fusion)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the HIP path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    iak_lib.load()
+
+    B = args.batch
+    rgb = make_cell_batch(B, dev, seed=0x1A2B3C4D + rank)
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    pipe = Pipeline(W, H, B, P_A, fused=not args.stagewise)
+    hist_local = torch.zeros(256, dtype=torch.int64, device=dev)
+    hist_total = torch.zeros(256, dtype=torch.int64, device=dev)
+
+    def step():
+        hist_local.zero_()
+        pipe.run(rgb, out=out, hist_sum=hist_local)
+        if dist is not None:
+            # dataset-level histogram: the one exchange of the path (2 KiB, latency-bound)
+            dist.all_reduce(hist_local, op=dist.ReduceOp.SUM)
+        hist_total.copy_(hist_local)
+
+    for _ in range(args.warmup):
+        step()
+    slots = min(max(args.steps, 1), 256)
+    pipe.set_timing(slots)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-launch-group durations from the HIP events recorded inside the timed steps
+    nrec = min(args.steps, slots)
+    acc = None
+    for sl in range(nrec):
+        t = pipe.timings(sl)
+        if acc is None:
+            acc = [[n, 0.0, b] for n, _, b in t]
+        for i, (_, ms, _) in enumerate(t):
+            acc[i][1] += ms
+    groups = [(n, ms / max(nrec, 1), b) for n, ms, b in acc] if acc else []
+
+    if rank == 0:
+        px_per_step = B * W * H * world
+        value = px_per_step * args.steps / dt / 1e6
+        dom = max(groups, key=lambda g: g[1]) if groups else None
+        roofline = None
+        if dom:
+            achieved = dom[2] * B * W * H / (dom[1] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_px": dom[2], "avg_ms": round(dom[1], 4)}
+            tr = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tr):
+                try:
+                    rec = json.load(open(tr)).get(dom[0])
+                    if rec and rec.get("batch") == B:
+                        roofline["traffic"] = rec["hbm_bytes_per_launch"]
+                except Exception:
+                    pass
+        line = {
+            "metric": "Mpixels/sec (whole node) full filter pipeline", "value": round(value, 1), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"batch of {B} 768x568 RGB cell-like images per GPU, full pipeline "
+                                   "(gray, histogram, equalize, gaussian noise, salt-and-pepper 50, 3x3 linear, "
+                                   "3x3 median, sobel), device-resident",
+                       "images_per_gpu": B, "mode": "stagewise" if args.stagewise else "fused",
+                       "parallelism": f"image-wise shards x{world}, dataset-histogram all-reduce per step"},
+            "pipeline_frac_of_hbm_roofline": round(value * 1e6 * P_A_BYTES_PER_PX / world / (HBM_PEAK_GBS * 1e9), 4),
+            "groups": [{"name": n, "ms": round(ms, 4), "alg_GBps": round(b * B * W * H / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+                       for n, ms, b in groups],
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            threads = max(1, min(threads, os.cpu_count() or 1, B))
+            base, ref_out, n = cpu_baseline(rgb, threads)
+            # the sample doubles as a full-size parity check of the timed path
+            base["matches_gpu"] = bool(np.array_equal(out[:n].cpu().numpy(), ref_out))
+            line["cpu_baseline"] = base
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,584 @@
+// Batched pipeline executor: the device-resident replacement of the per-image, per-operation
+// loop in the reference's driver (test/test.cu:266-564).  A plan is made once
+// (iak_pipeline_create); a run enqueues a fixed list of launch groups on one stream and
+// touches no allocator and no host synchronisation.
+//
+// Fused mode merges what the operation list allows without changing any result:
+//   * grayscale + per-image histogram are one pass;
+//   * a run of per-pixel operations (equalisation, quantisation, thresholds, Gaussian noise,
+//     salt-and-pepper) is one read-modify-write pass.  The 256-entry work between them
+//     (cdf map, Otsu threshold, mean/std, amplitude table) is done by a one-workgroup-per-
+//     image prologue; a histogram needed after a table look-up is obtained by pushing the
+//     previous histogram through the table, not by another pass over the image.
+#include "iak_common.hpp"
+#include "iak_device_fns.hpp"
+
+#include <new>
+#include <string>
+#include <vector>
+
+namespace iak {
+
+// ---- per-pixel chain ---------------------------------------------------------------------
+enum { C_EQUALIZE = 1, C_OTSU = 2, C_CONST_LUT = 3, C_GAUSS = 4, C_SP = 5 };
+#define CHAIN_MAX 6
+
+struct ChainStage {
+    int type;
+    float mean, stddev;   // C_GAUSS
+    const uint8_t *plane; // C_GAUSS: rv plane, C_SP: code plane
+    int lut_slot;         // C_CONST_LUT: index into ChainDesc::const_lut
+};
+struct ChainDesc {
+    int n;
+    ChainStage st[CHAIN_MAX];
+    uint8_t const_lut[2][256];  // at most two constant tables per chain
+};
+
+// Per image (one workgroup of 256 lanes): walk the chain once on the histogram, producing
+// every stage's table.  tables: [B][CHAIN_MAX][256] uint16 (LUT stages use the low byte).
+__global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *__restrict__ hist_in, int numPixels,
+                                                         ChainDesc d, uint16_t *__restrict__ tables) {
+    __shared__ uint32_t h[256];    // current histogram, bin 0 empty
+    __shared__ uint32_t h2[256];
+    __shared__ int32_t map[256];
+    __shared__ float ms[2];
+    const int b = blockIdx.x;
+    const int v = threadIdx.x;
+    h[v] = hist_in ? hist_in[(long long)b * 256 + v] : 0u;
+    __syncthreads();
+    uint16_t *tb = tables + (long long)b * CHAIN_MAX * 256;
+    for (int s = 0; s < d.n; s++) {
+        const ChainStage st = d.st[s];
+        if (st.type == C_GAUSS) {
+            if (v == 0) {
+                float mean = st.mean, sd = st.stddev;
+                if (mean == -1 || sd == -1) mean_std_from_hist(h, numPixels, &mean, &sd);
+                ms[0] = mean;
+                ms[1] = sd * sd;
+            }
+            __syncthreads();
+            tb[s * 256 + v] = gauss_entry(v, ms[0], ms[1]);
+            __syncthreads();
+            continue;  // position-dependent from here on: the planner never asks for h again
+        }
+        if (st.type == C_SP) continue;
+        // look-up stages: build the table, then push the histogram through it
+        if (st.type == C_EQUALIZE) {
+            if (v == 0) eq_map_from_hist(h, map, numPixels);
+        } else if (st.type == C_OTSU) {
+            if (v == 0) map[0] = otsu_threshold_from_hist(h, numPixels);
+        }
+        __syncthreads();
+        uint32_t lut;
+        if (st.type == C_EQUALIZE) lut = (uint32_t)map[v] & 0xffu;
+        else if (st.type == C_OTSU) lut = (v > map[0]) ? 255u : 0u;
+        else lut = d.const_lut[st.lut_slot][v];
+        tb[s * 256 + v] = (uint16_t)lut;
+        h2[v] = 0;
+        __syncthreads();
+        // zeros are not in h: bin 0 holds numPixels - sum(others)
+        uint32_t cnt = h[v];
+        if (v == 0) {
+            uint32_t nz = 0;
+            for (int i = 1; i < 256; i++) nz += h[i];
+            cnt = (uint32_t)numPixels - nz;
+        }
+        if (cnt) atomicAdd(&h2[lut], cnt);
+        __syncthreads();
+        h[v] = (v == 0) ? 0u : h2[v];
+        __syncthreads();
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                          long long N, long long in_stride, long long out_stride,
+                                                          ChainDesc d, const uint16_t *__restrict__ tables) {
+    __shared__ uint8_t lut[CHAIN_MAX][256];
+    __shared__ uint16_t tab[CHAIN_MAX][256];
+    const int b = blockIdx.y;
+    const uint16_t *tb = tables + (long long)b * CHAIN_MAX * 256;
+    for (int s = 0; s < d.n; s++) {
+        if (d.st[s].type == C_GAUSS) tab[s][threadIdx.x] = tb[s * 256 + threadIdx.x];
+        else if (d.st[s].type != C_SP) lut[s][threadIdx.x] = (uint8_t)tb[s * 256 + threadIdx.x];
+    }
+    __syncthreads();
+    const uint8_t *src = in + (long long)b * in_stride;
+    uint8_t *dst = out + (long long)b * out_stride;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    long long scalar_from = 0;
+    if (VEC) {
+        const long long nchunks = N >> 4;
+        for (long long c = tid; c < nchunks; c += nthreads) {
+            const long long off = c << 4;
+            u32x4 v = ld16(src + off);
+            for (int s = 0; s < d.n; s++) {
+                const int type = d.st[s].type;
+                if (type == C_GAUSS) {
+                    u32x4 r = ld16(d.st[s].plane + off);
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        uint32_t o = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            uint32_t e = tab[s][byte_of(r[w], k)];
+                            uint32_t y = (e & 0x100u) ? 0u : ((byte_of(v[w], k) + e) & 0xffu);
+                            o |= y << (8 * k);
+                        }
+                        v[w] = o;
+                    }
+                } else if (type == C_SP) {
+                    u32x4 c4 = ld16(d.st[s].plane + off);
+#pragma unroll
+                    for (int w = 0; w < 4; w++) v[w] = sp4(v[w], c4[w]);
+                } else {
+                    v = lut16(lut[s], v);
+                }
+            }
+            st16(dst + off, v);
+        }
+        scalar_from = nchunks << 4;
+    }
+    for (long long t = scalar_from + tid; t < N; t += nthreads) {
+        uint32_t p = src[t];
+        for (int s = 0; s < d.n; s++) {
+            const int type = d.st[s].type;
+            if (type == C_GAUSS) {
+                uint32_t e = tab[s][d.st[s].plane[t]];
+                p = (e & 0x100u) ? 0u : ((p + e) & 0xffu);
+            } else if (type == C_SP) {
+                uint32_t c = d.st[s].plane[t];
+                p = c == 0 ? p : (c == 2 ? 255u : 0u);
+            } else {
+                p = lut[s][p];
+            }
+        }
+        dst[t] = (uint8_t)p;
+    }
+}
+
+// dataset histogram: sum[v] += sum_b hist[b][v]
+__global__ __launch_bounds__(256) void hist_accumulate_kernel(const uint32_t *__restrict__ hist, int B,
+                                                              unsigned long long *__restrict__ sum) {
+    const int v = threadIdx.x;
+    unsigned long long s = 0;
+    for (int b = 0; b < B; b++) s += hist[(long long)b * 256 + v];
+    sum[v] += s;
+}
+
+}  // namespace iak
+
+using namespace iak;
+
+// ---- plan ---------------------------------------------------------------------------------
+namespace {
+
+struct OpCopy {
+    iak_op op;
+    std::vector<float> f;
+    std::vector<int> i;
+};
+
+enum GroupKind { G_GRAYHIST, G_HIST, G_CHAIN, G_OP };
+
+struct Group {
+    GroupKind kind;
+    std::string name;
+    long long alg_bytes;  // algorithmic bytes per pixel of the operations in the group
+    int op_index = -1;    // G_OP
+    ChainDesc chain;      // G_CHAIN
+    bool chain_needs_hist = false;
+};
+
+bool is_pointwise(int t) {
+    return t == IAK_OP_EQUALIZE || t == IAK_OP_GAUSS || t == IAK_OP_SALT_PEPPER || t == IAK_OP_THRESHOLD ||
+           t == IAK_OP_OTSU || t == IAK_OP_QUANTIZE;
+}
+bool needs_hist(const iak_op &o) {
+    return o.type == IAK_OP_EQUALIZE || o.type == IAK_OP_OTSU ||
+           (o.type == IAK_OP_GAUSS && (o.mean == -1 || o.stddev == -1));
+}
+bool hist_survives(int t) {  // histogram after the stage follows from the one before it
+    return t == IAK_OP_EQUALIZE || t == IAK_OP_THRESHOLD || t == IAK_OP_OTSU || t == IAK_OP_QUANTIZE;
+}
+const char *op_name(int t) {
+    static const char *n[] = {"?", "equalize", "gauss", "salt_pepper", "linear", "average", "median", "sobel",
+                              "compass", "dilate", "erode", "threshold", "otsu", "quantize"};
+    return (t >= 1 && t <= 13) ? n[t] : "?";
+}
+// stage-wise compulsory traffic per pixel: every stage reads its input and writes its output;
+// the noise stages also read one plane byte
+long long op_alg_bytes(int t) {
+    if (t == IAK_OP_GAUSS || t == IAK_OP_SALT_PEPPER) return 3;
+    return 2;
+}
+
+}  // namespace
+
+struct iak_pipeline {
+    int W = 0, H = 0, maxB = 0, mode = 0;
+    long long N = 0;
+    std::vector<OpCopy> ops;
+    std::vector<Group> groups;
+    // device memory
+    uint8_t *bufA = nullptr, *bufB = nullptr;
+    uint32_t *hist = nullptr;   // [maxB][256] grayscale histograms
+    uint32_t *hist2 = nullptr;  // [maxB][256] histogram of an intermediate
+    int32_t *map = nullptr;     // [maxB][256]
+    int32_t *thr = nullptr;     // [maxB]
+    uint16_t *tables = nullptr; // [maxB][CHAIN_MAX][256]
+    uint32_t *x0 = nullptr, *x1 = nullptr;
+    uint8_t *rv = nullptr;
+    std::vector<std::pair<int, uint8_t *>> sp;  // level -> plane
+    // timing: `slots` sets of (groups + 1) events, run r records into set r % slots
+    int slots = 0;
+    std::vector<hipEvent_t> ev;
+    long long runs_timed = 0;
+
+    uint8_t *sp_plane(int level) const {
+        for (auto &e : sp)
+            if (e.first == level) return e.second;
+        return nullptr;
+    }
+};
+
+static void free_all(iak_pipeline *p) {
+    void *ptrs[] = {p->bufA, p->bufB, p->hist, p->hist2, p->map, p->thr, p->tables, p->x0, p->x1, p->rv};
+    for (void *q : ptrs) (void)hipFree(q);
+    for (auto &e : p->sp) (void)hipFree(e.second);
+    for (auto e : p->ev) (void)hipEventDestroy(e);
+}
+
+static int plan(iak_pipeline *p) {
+    p->groups.clear();
+    Group g0;
+    g0.kind = G_GRAYHIST;
+    g0.name = "gray+hist";
+    g0.alg_bytes = 4 + 1;
+    p->groups.push_back(g0);
+    const int n = (int)p->ops.size();
+    bool hist_known = true;  // of the current image, in p->hist (after gray) or p->hist2
+    int i = 0;
+    while (i < n) {
+        const iak_op &o = p->ops[i].op;
+        if (p->mode == IAK_PIPE_FUSED && is_pointwise(o.type)) {
+            Group g;
+            g.kind = G_CHAIN;
+            g.alg_bytes = 0;
+            g.chain.n = 0;
+            int luts = 0;
+            bool chain_hist = hist_known;  // histogram tracked through the chain
+            bool first = true;
+            while (i < n && is_pointwise(p->ops[i].op.type) && g.chain.n < CHAIN_MAX) {
+                const iak_op &q = p->ops[i].op;
+                if (needs_hist(q) && !chain_hist) {
+                    if (!first) break;  // needs a histogram of a noisy intermediate: new pass
+                    g.chain_needs_hist = true;  // a histogram pass on the chain's input comes first
+                    chain_hist = true;
+                }
+                if ((q.type == IAK_OP_THRESHOLD || q.type == IAK_OP_QUANTIZE) && luts >= 2) break;
+                ChainStage st{};
+                switch (q.type) {
+                case IAK_OP_EQUALIZE: st.type = C_EQUALIZE; break;
+                case IAK_OP_OTSU: st.type = C_OTSU; break;
+                case IAK_OP_THRESHOLD:
+                    st.type = C_CONST_LUT;
+                    st.lut_slot = luts;
+                    for (int v = 0; v < 256; v++) g.chain.const_lut[luts][v] = (v > q.iparam) ? 255 : 0;
+                    luts++;
+                    break;
+                case IAK_OP_QUANTIZE:
+                    st.type = C_CONST_LUT;
+                    st.lut_slot = luts;
+                    for (int v = 0; v < 256; v++) {
+                        uint8_t r = (uint8_t)v;
+                        for (int l = 0; l < q.iparam; l++)
+                            if (v >= q.ikernel[l * 3] && v < q.ikernel[l * 3 + 1]) {
+                                r = (uint8_t)q.ikernel[l * 3 + 2];
+                                break;
+                            }
+                        g.chain.const_lut[luts][v] = r;
+                    }
+                    luts++;
+                    break;
+                case IAK_OP_GAUSS:
+                    st.type = C_GAUSS;
+                    st.mean = q.mean;
+                    st.stddev = q.stddev;
+                    st.plane = p->rv;
+                    break;
+                case IAK_OP_SALT_PEPPER:
+                    st.type = C_SP;
+                    st.plane = p->sp_plane(q.iparam);
+                    break;
+                }
+                g.chain.st[g.chain.n++] = st;
+                g.alg_bytes += op_alg_bytes(q.type);
+                if (!g.name.empty()) g.name += "+";
+                g.name += op_name(q.type);
+                if (!hist_survives(q.type)) chain_hist = false;
+                first = false;
+                i++;
+            }
+            if (g.chain_needs_hist) {
+                Group gh;
+                gh.kind = G_HIST;
+                gh.name = "hist";
+                gh.alg_bytes = 1;
+                p->groups.push_back(gh);
+            }
+            p->groups.push_back(g);
+            hist_known = false;  // conservative: a later consumer re-measures
+            continue;
+        }
+        Group g;
+        g.kind = G_OP;
+        g.op_index = i;
+        g.name = op_name(o.type);
+        g.alg_bytes = op_alg_bytes(o.type) + (needs_hist(o) ? 1 : 0);
+        p->groups.push_back(g);
+        hist_known = false;
+        i++;
+    }
+    if ((int)p->groups.size() > IAK_PIPE_MAX_STAGES) return IAK_E_TOO_LARGE;
+    return 0;
+}
+
+extern "C" {
+
+int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op *ops, int nops,
+                        unsigned long long seed, int mode) {
+    if (!out || W <= 0 || H <= 0 || maxB <= 0 || nops < 0 || (nops > 0 && !ops)) return IAK_E_ARG;
+    if (mode != IAK_PIPE_STAGEWISE && mode != IAK_PIPE_FUSED) return IAK_E_ARG;
+    iak_pipeline *p = new (std::nothrow) iak_pipeline();
+    if (!p) return (int)hipErrorOutOfMemory;
+    p->W = W; p->H = H; p->maxB = maxB; p->mode = mode;
+    p->N = (long long)W * H;
+    bool any_noise = false;
+    for (int i = 0; i < nops; i++) {
+        OpCopy c;
+        c.op = ops[i];
+        const iak_op &o = ops[i];
+        int taps = o.kW * o.kH;
+        switch (o.type) {
+        case IAK_OP_LINEAR: case IAK_OP_AVERAGE:
+            if (!o.fkernel || o.kW < 1 || o.kH < 1) { delete p; return IAK_E_ARG; }
+            if (taps > IAK_MAX_TAPS) { delete p; return IAK_E_TOO_LARGE; }
+            c.f.assign(o.fkernel, o.fkernel + taps);
+            break;
+        case IAK_OP_MEDIAN: case IAK_OP_DILATE: case IAK_OP_ERODE:
+            if (!o.ikernel || o.kW < 1 || o.kH < 1) { delete p; return IAK_E_ARG; }
+            if (taps > IAK_MAX_TAPS) { delete p; return IAK_E_TOO_LARGE; }
+            c.i.assign(o.ikernel, o.ikernel + taps);
+            break;
+        case IAK_OP_QUANTIZE:
+            if (o.iparam < 0 || (o.iparam > 0 && !o.ikernel)) { delete p; return IAK_E_ARG; }
+            c.i.assign(o.ikernel, o.ikernel + 3 * o.iparam);
+            break;
+        case IAK_OP_GAUSS: case IAK_OP_SALT_PEPPER: any_noise = true; break;
+        case IAK_OP_EQUALIZE: case IAK_OP_SOBEL: case IAK_OP_COMPASS: case IAK_OP_THRESHOLD: case IAK_OP_OTSU: break;
+        default: delete p; return IAK_E_ARG;
+        }
+        p->ops.push_back(std::move(c));
+    }
+    for (auto &c : p->ops) {  // re-point at the copies
+        c.op.fkernel = c.f.empty() ? nullptr : c.f.data();
+        c.op.ikernel = c.i.empty() ? nullptr : c.i.data();
+    }
+    const size_t img = (size_t)p->N * (size_t)maxB;
+#define TRY(call)                                   \
+    do {                                            \
+        hipError_t e__ = (call);                    \
+        if (e__ != hipSuccess) {                    \
+            free_all(p);                            \
+            delete p;                               \
+            return (int)e__;                        \
+        }                                           \
+    } while (0)
+    TRY(hipMalloc((void **)&p->bufA, img));
+    TRY(hipMalloc((void **)&p->bufB, img));
+    TRY(hipMalloc((void **)&p->hist, sizeof(uint32_t) * 256 * (size_t)maxB));
+    TRY(hipMalloc((void **)&p->hist2, sizeof(uint32_t) * 256 * (size_t)maxB));
+    TRY(hipMalloc((void **)&p->map, sizeof(int32_t) * 256 * (size_t)maxB));
+    TRY(hipMalloc((void **)&p->thr, sizeof(int32_t) * (size_t)maxB));
+    TRY(hipMalloc((void **)&p->tables, sizeof(uint16_t) * 256 * CHAIN_MAX * (size_t)maxB));
+    if (any_noise) {
+        // setupRandomness (imageAnalysis.cu:740-746): once per pipeline, outside the runs
+        TRY(hipMalloc((void **)&p->x0, sizeof(uint32_t) * (size_t)p->N));
+        TRY(hipMalloc((void **)&p->x1, sizeof(uint32_t) * (size_t)p->N));
+        TRY(hipMalloc((void **)&p->rv, (size_t)p->N));
+        int rc = iak_rng_planes(p->x0, p->x1, p->N, seed, nullptr);
+        if (rc == 0) rc = iak_rv_plane(p->x0, p->rv, p->N, nullptr);
+        for (auto &c : p->ops)
+            if (rc == 0 && c.op.type == IAK_OP_SALT_PEPPER && !p->sp_plane(c.op.iparam)) {
+                uint8_t *pl = nullptr;
+                TRY(hipMalloc((void **)&pl, (size_t)p->N));
+                p->sp.emplace_back(c.op.iparam, pl);
+                rc = iak_sp_plane(p->x0, p->x1, pl, p->N, c.op.iparam, nullptr);
+            }
+        if (rc == 0) rc = (int)hipStreamSynchronize(nullptr);
+        if (rc != 0) { free_all(p); delete p; return rc; }
+    }
+#undef TRY
+    int rc = plan(p);
+    if (rc != 0) { free_all(p); delete p; return rc; }
+    *out = p;
+    return 0;
+}
+
+int iak_pipeline_destroy(iak_pipeline *p) {
+    if (!p) return 0;
+    free_all(p);
+    delete p;
+    return 0;
+}
+
+int iak_pipeline_set_timing(iak_pipeline *p, int slots) {
+    if (!p || slots < 0 || slots > 1024) return IAK_E_ARG;
+    for (auto e : p->ev) (void)hipEventDestroy(e);
+    p->ev.clear();
+    p->slots = 0;
+    p->runs_timed = 0;
+    const size_t per = p->groups.size() + 1;
+    for (size_t i = 0; i < per * (size_t)slots; i++) {
+        hipEvent_t e;
+        IAK_HIP(hipEventCreate(&e));
+        p->ev.push_back(e);
+    }
+    p->slots = slots;
+    return 0;
+}
+
+int iak_pipeline_timings(iak_pipeline *p, int slot, float *ms, const char **names, long long *alg_bytes_per_px,
+                         int cap) {
+    if (!p) return IAK_E_ARG;
+    const int n = (int)p->groups.size();
+    if (ms) {
+        if (slot < 0 || slot >= p->slots || slot >= p->runs_timed) return IAK_E_ARG;
+        const hipEvent_t *ev = p->ev.data() + (size_t)slot * (n + 1);
+        IAK_HIP(hipEventSynchronize(ev[n]));
+        for (int i = 0; i < n && i < cap; i++) IAK_HIP(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    }
+    for (int i = 0; i < n && i < cap; i++) {
+        if (names) names[i] = p->groups[i].name.c_str();
+        if (alg_bytes_per_px) alg_bytes_per_px[i] = p->groups[i].alg_bytes;
+    }
+    return n;
+}
+
+static int run_single_op(iak_pipeline *p, const iak_op &o, const uint8_t *src, uint8_t *dst, int B, void *stream) {
+    const int W = p->W, H = p->H;
+    const long long N = p->N;
+    switch (o.type) {
+    case IAK_OP_EQUALIZE: {
+        int rc = iak_hist(src, p->hist2, N, B, N, stream);
+        if (rc) return rc;
+        rc = iak_eq_map(p->hist2, p->map, (int)N, B, stream);
+        if (rc) return rc;
+        return iak_apply_map(src, dst, N, B, N, N, p->map, 256, stream);
+    }
+    case IAK_OP_GAUSS: {
+        const bool from_image = (o.mean == -1 || o.stddev == -1);
+        int rc = 0;
+        if (from_image) {
+            rc = iak_hist(src, p->hist2, N, B, N, stream);
+            if (rc) return rc;
+        }
+        rc = iak_gauss_table(p->hist2, (int)N, from_image ? B : 1, o.mean, o.stddev, p->tables, stream);
+        if (rc) return rc;
+        return iak_gauss_noise(src, dst, N, B, N, N, p->rv, p->tables, from_image ? 256 : 0, stream);
+    }
+    case IAK_OP_SALT_PEPPER: return iak_salt_pepper(src, dst, N, B, N, N, p->sp_plane(o.iparam), stream);
+    case IAK_OP_LINEAR: return iak_linear(src, dst, W, H, B, N, N, o.fkernel, o.kW, o.kH, IAK_LINEAR_CLAMP, stream);
+    case IAK_OP_AVERAGE: return iak_linear(src, dst, W, H, B, N, N, o.fkernel, o.kW, o.kH, IAK_LINEAR_AVERAGE, stream);
+    case IAK_OP_MEDIAN: return iak_median(src, dst, W, H, B, N, N, o.ikernel, o.kW, o.kH, stream);
+    case IAK_OP_SOBEL: return iak_sobel(src, dst, W, H, B, N, N, stream);
+    case IAK_OP_COMPASS: return iak_compass(src, dst, W, H, B, N, N, stream);
+    case IAK_OP_DILATE: return iak_dilate(src, dst, W, H, B, N, N, o.ikernel, o.kW, o.kH, stream);
+    case IAK_OP_ERODE: return iak_erode(src, dst, W, H, B, N, N, o.ikernel, o.kW, o.kH, stream);
+    case IAK_OP_THRESHOLD: return iak_threshold(src, dst, N, B, N, N, o.iparam, stream);
+    case IAK_OP_OTSU: {
+        int rc = iak_hist(src, p->hist2, N, B, N, stream);
+        if (rc) return rc;
+        rc = iak_otsu_threshold(p->hist2, p->thr, (int)N, B, stream);
+        if (rc) return rc;
+        return iak_threshold_per_image(src, dst, N, B, N, N, p->thr, stream);
+    }
+    case IAK_OP_QUANTIZE: return iak_quantize(src, dst, N, B, N, N, o.ikernel, o.iparam, stream);
+    }
+    return IAK_E_ARG;
+}
+
+int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, unsigned long long *hist_sum,
+                     uint32_t *gray_hist, void *stream) {
+    if (!p || !rgb || !out || B <= 0 || B > p->maxB) return IAK_E_ARG;
+    hipStream_t s = as_stream(stream);
+    const long long N = p->N;
+    const int ng = (int)p->groups.size();
+    // image-producing groups alternate between the two buffers; the last one writes `out`
+    int producers = 0;
+    for (auto &g : p->groups)
+        if (g.kind != G_HIST) producers++;
+    int produced = 0;
+    const uint8_t *cur = nullptr;
+    const uint32_t *cur_hist = nullptr;
+    uint32_t *ghist = gray_hist ? gray_hist : p->hist;
+    const hipEvent_t *ev = p->slots ? p->ev.data() + (size_t)(p->runs_timed % p->slots) * (ng + 1) : nullptr;
+    if (ev) IAK_HIP(hipEventRecord(ev[0], s));
+    for (int gi = 0; gi < ng; gi++) {
+        const Group &g = p->groups[gi];
+        uint8_t *dst = nullptr;
+        if (g.kind != G_HIST) {
+            produced++;
+            dst = (produced == producers) ? out : ((produced & 1) ? p->bufA : p->bufB);
+        }
+        int rc = 0;
+        switch (g.kind) {
+        case G_GRAYHIST:
+            rc = iak_gray_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, 0, s);
+            if (rc == 0 && hist_sum) {
+                hipLaunchKernelGGL(hist_accumulate_kernel, dim3(1), dim3(256), 0, s, ghist, B, hist_sum);
+                IAK_LAUNCH_CHECK();
+            }
+            cur_hist = ghist;
+            break;
+        case G_HIST:
+            rc = iak_hist(cur, p->hist2, N, B, N, s);
+            cur_hist = p->hist2;
+            break;
+        case G_CHAIN: {
+            bool wants = false;
+            for (int k = 0; k < g.chain.n; k++)
+                wants = wants || g.chain.st[k].type == C_EQUALIZE || g.chain.st[k].type == C_OTSU ||
+                        (g.chain.st[k].type == C_GAUSS && (g.chain.st[k].mean == -1 || g.chain.st[k].stddev == -1));
+            if (wants && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
+            hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, g.chain, p->tables);
+            IAK_LAUNCH_CHECK();
+            bool vec = aligned16(cur) && aligned16(dst) && N % 16 == 0;
+            for (int k = 0; k < g.chain.n; k++)
+                if (g.chain.st[k].plane) vec = vec && aligned16(g.chain.st[k].plane);
+            dim3 grid(blocks_x(vec ? N / 16 : N, 256, B), B);
+            if (vec)
+                hipLaunchKernelGGL((chain_apply_kernel<true>), grid, dim3(256), 0, s, cur, dst, N, N, N, g.chain, p->tables);
+            else
+                hipLaunchKernelGGL((chain_apply_kernel<false>), grid, dim3(256), 0, s, cur, dst, N, N, N, g.chain, p->tables);
+            IAK_LAUNCH_CHECK();
+            cur_hist = nullptr;
+            break;
+        }
+        case G_OP:
+            rc = run_single_op(p, p->ops[g.op_index].op, cur, dst, B, s);
+            cur_hist = nullptr;
+            break;
+        }
+        if (rc) return rc;
+        if (dst) cur = dst;
+        if (ev) IAK_HIP(hipEventRecord(ev[gi + 1], s));
+    }
+    if (ev) p->runs_timed++;
+    return 0;
+}
+
+}  // extern "C"

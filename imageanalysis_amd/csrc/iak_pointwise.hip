@@ -3,6 +3,7 @@
 // load/store (one dwordx4), a workgroup is 256 lanes (4 waves), the grid is
 // (blocks per image, B) with a grid-stride loop inside the image.
 #include "iak_common.hpp"
+#include "iak_device_fns.hpp"
 
 namespace iak {
 
@@ -57,16 +58,6 @@ struct LutTable {
     uint8_t v[256];
 };
 
-__device__ __forceinline__ u32x4 lut16(const uint8_t *lut, u32x4 px) {
-    u32x4 o;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        uint32_t x = px[w];
-        o[w] = pack4(lut[x & 0xff], lut[(x >> 8) & 0xff], lut[(x >> 16) & 0xff], lut[x >> 24]);
-    }
-    return o;
-}
-
 struct MapFn {  // out = (uchar)map[in], map int32[256] per image in global memory
     const int32_t *map;
     long long map_stride;
@@ -118,15 +109,6 @@ struct ThresholdFn {
 };
 
 // ---- salt and pepper from the code plane (0 keep, 1 pepper, 2 salt) ----------------------
-__device__ __forceinline__ uint32_t sp4(uint32_t px, uint32_t code) {
-    // per byte: any code bit set -> drop the pixel; code bit 1 set -> 255
-    uint32_t hit = (code | (code >> 1)) & 0x01010101u;
-    uint32_t salt = (code >> 1) & 0x01010101u;
-    uint32_t hitmask = (hit << 8) - hit;
-    uint32_t saltmask = (salt << 8) - salt;
-    return (px & ~hitmask) | saltmask;
-}
-
 struct SaltPepperFn {
     const uint8_t *sp;
     __device__ void begin(int) {}

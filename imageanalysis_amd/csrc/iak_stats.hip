@@ -5,6 +5,7 @@
 // Arithmetic is deliberately sequential where the reference's is (float32 cdf, Otsu's
 // running sums): a parallel scan would round differently.
 #include "iak_common.hpp"
+#include "iak_device_fns.hpp"
 
 #include <mutex>
 
@@ -14,43 +15,7 @@ namespace iak {
 __global__ void eq_map_kernel(const uint32_t *__restrict__ hist, int32_t *__restrict__ map, int numPixels, int B) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const uint32_t *h = hist + (long long)b * 256;
-    int32_t *m = map + (long long)b * 256;
-    float cdf = 0.0f;
-    const float n = (float)numPixels;
-    for (int i = 0; i < 256; i++) {
-        float pdf = (float)(int)h[i] / n;
-        cdf = (i > 0) ? (pdf + cdf) : pdf;
-        m[i] = (int)(cdf * 255);
-    }
-}
-
-// ---- Otsu's loop (imageAnalysis.cu:255-277); hist has bin 0 empty ----------------------------
-__device__ int otsu_threshold_from_hist(const uint32_t *h, int totalPixels) {
-    // sum of pixel values: zeros add nothing, so the zero-less histogram gives it exactly
-    long long sum64 = 0;
-    for (int i = 1; i < 256; i++) sum64 += (long long)h[i] * i;
-    int sum = (int)sum64;
-    float varMax = 0;
-    int threshold = 0;
-    int backgroundSum = 0;
-    int nB = 0;
-    for (int i = 0; i < 256; i++) {
-        int hi = (i == 0) ? 0 : (int)h[i];
-        nB += hi;
-        if (nB == 0) continue;
-        int nF = totalPixels - nB;
-        if (nF == 0) continue;
-        backgroundSum += i * hi;
-        float bMean = (float)(backgroundSum / nB);
-        float fMean = (float)((sum - backgroundSum) / nF);
-        float bcv = (float)nB * (float)nF * (bMean - fMean) * (bMean - fMean);
-        if (bcv > varMax) {
-            varMax = bcv;
-            threshold = i;
-        }
-    }
-    return threshold;
+    eq_map_from_hist(hist + (long long)b * 256, map + (long long)b * 256, numPixels);
 }
 
 __global__ void otsu_kernel(const uint32_t *__restrict__ hist, int32_t *__restrict__ thr, int numPixels, int B) {
@@ -59,73 +24,10 @@ __global__ void otsu_kernel(const uint32_t *__restrict__ hist, int32_t *__restri
     thr[b] = otsu_threshold_from_hist(hist + (long long)b * 256, numPixels);
 }
 
-// ---- calculateMeanAndStdDev (imageAnalysis.cu:106-128) from a zero-less histogram -------------
-__device__ void mean_std_from_hist(const uint32_t *h, int numPixels, float *mean, float *stddev) {
-    long long sum = 0, nonzero = 0;
-    for (int v = 1; v < 256; v++) {
-        sum += (long long)h[v] * v;
-        nonzero += h[v];
-    }
-    const long long zeros = (long long)numPixels - nonzero;
-    const float m = (float)sum / (float)numPixels;
-    double acc = 0.0;
-    for (int v = 0; v < 256; v++) {
-        double d = (double)((float)v - m);
-        long long c = (v == 0) ? zeros : (long long)h[v];
-        acc += (double)c * (d * d);
-    }
-    float variance = (float)acc / (float)((long long)numPixels - 1);
-    *mean = m;
-    *stddev = sqrtf(variance);
-}
-
 __global__ void mean_std_kernel(const uint32_t *__restrict__ hist, float *__restrict__ out, int numPixels, int B) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     mean_std_from_hist(hist + (long long)b * 256, numPixels, &out[2 * b], &out[2 * b + 1]);
-}
-
-// exp in double from + - * only (no fused multiply-add, no library call), so the bits do
-// not depend on a maths library.  |error| ~1e-16 relative.
-__device__ double portable_exp(double x) {
-    if (x != x) return x;
-    if (x > 709.0) return __longlong_as_double(0x7ff0000000000000LL);
-    if (x < -708.0) return 0.0;
-    const double INV_LN2 = 1.4426950408889634074;
-    const double LN2_HI = 6.93147180369123816490e-01;
-    const double LN2_LO = 1.90821492927058770002e-10;
-    double kf = x * INV_LN2;
-    long long k = (long long)(kf + (kf < 0 ? -0.5 : 0.5));
-    double dk = (double)k;
-    double r = (x - dk * LN2_HI) - dk * LN2_LO;
-    double p = 1.0 / 6227020800.0;
-    p = p * r + 1.0 / 479001600.0;
-    p = p * r + 1.0 / 39916800.0;
-    p = p * r + 1.0 / 3628800.0;
-    p = p * r + 1.0 / 362880.0;
-    p = p * r + 1.0 / 40320.0;
-    p = p * r + 1.0 / 5040.0;
-    p = p * r + 1.0 / 720.0;
-    p = p * r + 1.0 / 120.0;
-    p = p * r + 1.0 / 24.0;
-    p = p * r + 1.0 / 6.0;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
-    if (k < -1022) return 0.0;
-    if (k > 1023) return __longlong_as_double(0x7ff0000000000000LL);
-    return p * __longlong_as_double((long long)(k + 1023) << 52);
-}
-
-// imageAnalysis.cu:841 for one draw value
-__device__ uint16_t gauss_entry(int rv, float mean, float variance) {
-    float d = (float)rv - mean;
-    float q = (d * d) / (2 * variance);
-    float x = -1.0f * q;
-    float e = (float)portable_exp((double)x);
-    float noise = roundf(255 * e);
-    if (noise != noise) return 0x100;
-    return (uint16_t)(((uint32_t)(int)noise) & 0xffu);
 }
 
 // one workgroup (256 lanes) per image
@@ -236,12 +138,6 @@ __global__ __launch_bounds__(256) void rng_planes_kernel(uint32_t *__restrict__ 
     uint32_t n5 = (n4 ^ (n4 << 4)) ^ (tt ^ (tt << 1));
     d += 362437u;
     x1[t] = n5 + d;
-}
-
-// curand_uniform: x * 2^-32 + 2^-33 as two float operations
-__device__ __forceinline__ float xw_uniform(uint32_t x) {
-    float f = (float)x * 2.3283064e-10f;
-    return f + (2.3283064e-10f / 2.0f);
 }
 
 __global__ __launch_bounds__(256) void rv_plane_kernel(const uint32_t *__restrict__ x0, uint8_t *__restrict__ rv, long long N) {

@@ -8,6 +8,15 @@ LIB_PATH = os.path.join(_HERE, "lib", "libiak.so")
 
 IAK_E_ARG, IAK_E_UNSUPPORTED, IAK_E_TOO_LARGE = -1, -2, -3
 IAK_LINEAR_CLAMP, IAK_LINEAR_AVERAGE = 0, 1
+IAK_PIPE_STAGEWISE, IAK_PIPE_FUSED = 0, 1
+(IAK_OP_EQUALIZE, IAK_OP_GAUSS, IAK_OP_SALT_PEPPER, IAK_OP_LINEAR, IAK_OP_AVERAGE, IAK_OP_MEDIAN, IAK_OP_SOBEL,
+ IAK_OP_COMPASS, IAK_OP_DILATE, IAK_OP_ERODE, IAK_OP_THRESHOLD, IAK_OP_OTSU, IAK_OP_QUANTIZE) = range(1, 14)
+
+
+class IakOp(C.Structure):
+    """iak_op of include/iak.h."""
+    _fields_ = [("type", C.c_int), ("kW", C.c_int), ("kH", C.c_int), ("fkernel", C.c_void_p),
+                ("ikernel", C.c_void_p), ("iparam", C.c_int), ("mean", C.c_float), ("stddev", C.c_float)]
 
 _vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 
@@ -45,6 +54,11 @@ SIGNATURES = {
     "iak_compass": [_vp, _vp, _i, _i, _i, _ll, _ll, _vp],
     "iak_dilate": [_vp, _vp, _i, _i, _i, _ll, _ll, _vp, _i, _i, _vp],
     "iak_erode": [_vp, _vp, _i, _i, _i, _ll, _ll, _vp, _i, _i, _vp],
+    "iak_pipeline_create": [C.POINTER(_vp), _i, _i, _i, _vp, _i, C.c_ulonglong, _i],
+    "iak_pipeline_destroy": [_vp],
+    "iak_pipeline_run": [_vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "iak_pipeline_set_timing": [_vp, _i],
+    "iak_pipeline_timings": [_vp, _i, _vp, _vp, _vp, _i],
 }
 _RESTYPE = {"iak_error_string": C.c_char_p}
 

@@ -150,6 +150,65 @@ int iak_dilate(const uint8_t *in, uint8_t *out, int W, int H, int B, long long i
 int iak_erode(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
               long long out_stride, const int *se, int kW, int kH, void *stream);
 
+
+/* ---- batched pipeline executor ------------------------------------------------------------
+ * Replaces the per-image / per-operation loop of executeOperations (test/test.cu:266-564)
+ * for a whole batch that is resident on the device: grayscale (luminance) + histogram,
+ * then the configured operations in order, with no per-operation allocation, copy or
+ * synchronisation.  Results are identical to calling the entry points above one after
+ * the other on every image. */
+enum {
+    IAK_OP_EQUALIZE = 1,    /* test.cu:404-419  histogram-equalization */
+    IAK_OP_GAUSS = 2,       /* test.cu:375-389  gaussian-noise: mean, stddev (-1: from image) */
+    IAK_OP_SALT_PEPPER = 3, /* test.cu:390-403  salt-and-pepper: iparam = intensity */
+    IAK_OP_LINEAR = 4,      /* test.cu:330-344  linear-filter: fkernel, kW, kH */
+    IAK_OP_AVERAGE = 5,     /* test.cu:345-359  average-filter */
+    IAK_OP_MEDIAN = 6,      /* test.cu:360-374  median-filter: ikernel = weights */
+    IAK_OP_SOBEL = 7,       /* test.cu:444-456 */
+    IAK_OP_COMPASS = 8,     /* test.cu:457-469 */
+    IAK_OP_DILATE = 9,      /* test.cu:470-484  ikernel = structuring element */
+    IAK_OP_ERODE = 10,      /* test.cu:485-499 */
+    IAK_OP_THRESHOLD = 11,  /* test.cu:500-509  iparam = threshold */
+    IAK_OP_OTSU = 12,       /* test.cu:510-518 */
+    IAK_OP_QUANTIZE = 13    /* test.cu:420-443  ikernel = levels {min,max,val}, iparam = numLevels */
+};
+typedef struct {
+    int type;
+    int kW, kH;
+    const float *fkernel; /* HOST */
+    const int *ikernel;   /* HOST */
+    int iparam;
+    float mean, stddev;
+} iak_op;
+
+#define IAK_PIPE_STAGEWISE 0 /* one launch (or more) per operation, every intermediate image written */
+#define IAK_PIPE_FUSED 1     /* runs of per-pixel operations and runs of 3x3 stencils share one pass */
+#define IAK_PIPE_MAX_STAGES 64
+
+typedef struct iak_pipeline iak_pipeline;
+/* Plans the pipeline for batches of up to maxB images of W x H and allocates everything a
+ * run needs (two image buffers, histograms, tables, the random planes for `seed`).
+ * This call allocates and synchronises; iak_pipeline_run does neither. */
+int iak_pipeline_create(iak_pipeline **p, int W, int H, int maxB, const iak_op *ops, int nops,
+                        unsigned long long seed, int mode);
+int iak_pipeline_destroy(iak_pipeline *p);
+/* rgb: B planar RGB images (stride 3*W*H); out: B result images (stride W*H).
+ * hist_sum: DEVICE array of 256 uint64, or NULL; the batch's grayscale-image histogram
+ * (bin 0 empty) is ADDED to it -- the dataset histogram a multi-GPU job all-reduces.
+ * gray_hist: DEVICE [B][256] uint32 per-image grayscale histograms, or NULL. */
+int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B,
+                     unsigned long long *hist_sum, uint32_t *gray_hist, void *stream);
+/* Per-launch-group timing.  set_timing(p, slots) (re)creates `slots` sets of HIP events
+ * (0 disables; this call allocates events, runs do not); run number r then records one event
+ * between launch groups into set r % slots, counting runs from the set_timing call.
+ * timings(p, slot, ...) waits for that set's last event and fills up to cap entries:
+ * ms[] (may be NULL to query names only), names[], alg_bytes_per_px[] (the stage-wise
+ * compulsory traffic of the operations in the group).  Returns the number of groups, or a
+ * negative error. */
+int iak_pipeline_set_timing(iak_pipeline *p, int slots);
+int iak_pipeline_timings(iak_pipeline *p, int slot, float *ms, const char **names,
+                         long long *alg_bytes_per_px, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,120 @@
+"""The batched executor (stage-wise and fused) against the oracle's pipeline, bit for bit,
+on small batches; and the configured pipelines of the reference's JSON configs."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+GAUSS16 = [1 / 16, 2 / 16, 1 / 16, 2 / 16, 4 / 16, 2 / 16, 1 / 16, 2 / 16, 1 / 16]
+ONES9 = [1] * 9
+CROSS = [0, 1, 0, 1, 1, 1, 0, 1, 0]
+
+# op dicts are shared by the executor and the oracle (same field names)
+P_A = [
+    {"type": O.OP_EQUALIZE},
+    {"type": O.OP_GAUSS, "mean": -1.0, "stddev": -1.0},
+    {"type": O.OP_SALT_PEPPER, "iparam": 50},
+    {"type": O.OP_LINEAR, "kW": 3, "kH": 3, "fkernel": GAUSS16},
+    {"type": O.OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": ONES9},
+    {"type": O.OP_SOBEL},
+]
+P_C = [
+    {"type": O.OP_OTSU},
+    {"type": O.OP_SOBEL},
+    {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": ONES9},
+    {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": CROSS},
+]
+INPUT_JSON = [  # test/configs/input.json:11-145 without kMeans / feature-extract
+    {"type": O.OP_GAUSS, "mean": -1.0, "stddev": -1.0},
+    {"type": O.OP_EQUALIZE},
+    {"type": O.OP_QUANTIZE, "ikernel": [10, 20, 15, 30, 250, 77], "iparam": 2},
+    {"type": O.OP_LINEAR, "kW": 3, "kH": 3, "fkernel": [1, 1, 1, 10, 1, 1, 1, 1, 1]},
+    {"type": O.OP_AVERAGE, "kW": 3, "kH": 3, "fkernel": [1, 1, 1, 10, 1, 1, 1, 1, 1]},
+    {"type": O.OP_SALT_PEPPER, "iparam": 50},
+    {"type": O.OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": ONES9},
+    {"type": O.OP_SOBEL},
+    {"type": O.OP_COMPASS},
+    {"type": O.OP_THRESHOLD, "iparam": 40},
+    {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": CROSS},
+    {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": CROSS},
+    {"type": O.OP_OTSU},
+]
+CHAINS = {
+    "P-A": P_A,
+    "P-C": P_C,
+    "input.json": INPUT_JSON,
+    "empty": [],
+    "lut-run": [{"type": O.OP_EQUALIZE}, {"type": O.OP_QUANTIZE, "ikernel": [0, 100, 50, 100, 256, 200], "iparam": 2},
+                {"type": O.OP_EQUALIZE}, {"type": O.OP_OTSU}],
+    "noise-then-stats": [{"type": O.OP_SALT_PEPPER, "iparam": 7}, {"type": O.OP_EQUALIZE},
+                         {"type": O.OP_GAUSS, "mean": -1.0, "stddev": 4.0}, {"type": O.OP_GAUSS, "mean": -1.0, "stddev": -1.0},
+                         {"type": O.OP_OTSU}],
+    "fixed-gauss": [{"type": O.OP_GAUSS, "mean": 120.0, "stddev": 30.0}, {"type": O.OP_THRESHOLD, "iparam": 100},
+                    {"type": O.OP_THRESHOLD, "iparam": 10}, {"type": O.OP_THRESHOLD, "iparam": 200},
+                    {"type": O.OP_SALT_PEPPER, "iparam": 3}, {"type": O.OP_SALT_PEPPER, "iparam": 50}],
+    "big-stencils": [{"type": O.OP_LINEAR, "kW": 11, "kH": 11, "fkernel": [1.0 / 121] * 121},
+                     {"type": O.OP_MEDIAN, "kW": 7, "kH": 7, "ikernel": [1] * 49}],
+}
+
+
+@pytest.fixture(scope="module")
+def Pipeline():
+    assert torch.cuda.is_available()
+    from imageanalysis_amd.pipeline import Pipeline as P
+    return P
+
+
+@pytest.mark.parametrize("name", list(CHAINS))
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("W,H,kind", [(64, 48, "C"), (37, 23, "U"), (768, 40, "C")])
+def test_pipeline_matches_oracle(Pipeline, name, fused, W, H, kind):
+    ops = CHAINS[name]
+    B = 3
+    rgb = synth.rgb_batch(kind, W, H, B)
+    x0, x1 = O.xorwow_planes(W * H)
+    want, want_hist = O.pipeline(rgb, ops, x0, x1)
+    p = Pipeline(W, H, B + 1, ops, fused=fused)
+    hist_sum = torch.zeros(256, dtype=torch.int64, device="cuda")
+    gray_hist = torch.empty((B, 256), dtype=torch.int32, device="cuda")
+    got = p.run(torch.from_numpy(rgb).cuda(), hist_sum=hist_sum, gray_hist=gray_hist).cpu().numpy()
+    for b in range(B):
+        if not np.array_equal(got[b], want[b]):
+            bad = np.argwhere(got[b] != want[b])
+            raise AssertionError(f"{name} fused={fused} image {b}: {len(bad)} mismatches, first {bad[0]}")
+    assert np.array_equal(hist_sum.cpu().numpy(), want_hist)
+    for b in range(B):
+        assert np.array_equal(gray_hist[b].cpu().numpy(), O.hist(O.gray(rgb[b], 0)))
+    # a second run accumulates the dataset histogram and reproduces the images
+    got2 = p.run(torch.from_numpy(rgb).cuda(), hist_sum=hist_sum).cpu().numpy()
+    assert np.array_equal(got2, got)
+    assert np.array_equal(hist_sum.cpu().numpy(), 2 * want_hist)
+    p.close()
+
+
+def test_pipeline_smaller_batch_than_planned(Pipeline):
+    W, H = 64, 48
+    rgb = synth.rgb_batch("C", W, H, 5)
+    x0, x1 = O.xorwow_planes(W * H)
+    p = Pipeline(W, H, 5, P_A, fused=True)
+    full = p.run(torch.from_numpy(rgb).cuda()).cpu().numpy()
+    part = p.run(torch.from_numpy(rgb[:2]).cuda()).cpu().numpy()
+    want, _ = O.pipeline(rgb, P_A, x0, x1)
+    assert np.array_equal(full, want) and np.array_equal(part, want[:2])
+
+
+def test_pipeline_timings(Pipeline):
+    W, H = 64, 48
+    rgb = torch.from_numpy(synth.rgb_batch("C", W, H, 2)).cuda()
+    p = Pipeline(W, H, 2, P_A, fused=True)
+    p.set_timing(2)
+    p.run(rgb)
+    p.run(rgb)
+    t = p.timings(1)
+    names = [n for n, _, _ in t]
+    assert names[0] == "gray+hist" and "equalize+gauss+salt_pepper" in names
+    assert sum(b for _, _, b in t) == 19  # stage-wise compulsory bytes per pixel of this pipeline
+    assert all(ms >= 0 for _, ms, _ in t)
