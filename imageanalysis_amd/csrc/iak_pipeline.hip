@@ -159,13 +159,17 @@ __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restr
     }
 }
 
-// dataset histogram: sum[v] += sum_b hist[b][v]
+// dataset histogram: sum[v] += sum_b hist[b][v]; each workgroup folds 8 images
+#define ACC_IMAGES 8
 __global__ __launch_bounds__(256) void hist_accumulate_kernel(const uint32_t *__restrict__ hist, int B,
                                                               unsigned long long *__restrict__ sum) {
     const int v = threadIdx.x;
+    const int b0 = blockIdx.x * ACC_IMAGES;
     unsigned long long s = 0;
-    for (int b = 0; b < B; b++) s += hist[(long long)b * 256 + v];
-    sum[v] += s;
+#pragma unroll
+    for (int i = 0; i < ACC_IMAGES; i++)
+        if (b0 + i < B) s += hist[(long long)(b0 + i) * 256 + v];
+    if (s) atomicAdd(&sum[v], s);
 }
 
 }  // namespace iak
@@ -539,7 +543,8 @@ int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, u
         case G_GRAYHIST:
             rc = iak_gray_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, 0, s);
             if (rc == 0 && hist_sum) {
-                hipLaunchKernelGGL(hist_accumulate_kernel, dim3(1), dim3(256), 0, s, ghist, B, hist_sum);
+                hipLaunchKernelGGL(hist_accumulate_kernel, dim3((B + ACC_IMAGES - 1) / ACC_IMAGES), dim3(256), 0, s, ghist, B,
+                                   hist_sum);
                 IAK_LAUNCH_CHECK();
             }
             cur_hist = ghist;

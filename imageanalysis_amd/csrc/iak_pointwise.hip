@@ -271,6 +271,30 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t *__restrict__ i
     hist_flush(sh, hist + (long long)b * 256);
 }
 
+// calcMSQE's arrayDifference (imageAnalysis.cu:780-786) and its byte sum
+__global__ __launch_bounds__(256) void msqe_kernel(const uint8_t *__restrict__ in, const uint8_t *__restrict__ out,
+                                                   const uint32_t *__restrict__ hist, uint32_t *__restrict__ sums,
+                                                   long long N, long long in_stride, long long out_stride) {
+    __shared__ double f[256];
+    __shared__ uint32_t part[4];
+    const int b = blockIdx.y;
+    f[threadIdx.x] = (double)(int)hist[(long long)b * 256 + threadIdx.x] / 255.0;
+    __syncthreads();
+    const uint8_t *a = in + (long long)b * in_stride;
+    const uint8_t *c = out + (long long)b * out_stride;
+    uint32_t acc = 0;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < N; t += (long long)gridDim.x * blockDim.x) {
+        const int p = a[t];
+        const int d = p - (int)c[t];
+        const double v = round((double)(d * d) * f[p]);
+        acc += ((uint32_t)(int)v) & 0xffu;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sums[b], part[0] + part[1] + part[2] + part[3]);
+}
+
 // A workgroup's 32 KiB table and its 256-atomic merge are amortised over the pixels it
 // streams: give each at least ~64K pixels, and keep the whole launch near 2-4K workgroups.
 static int hist_blocks_x(long long N, int B) {
@@ -327,6 +351,17 @@ int iak_hist(const uint8_t *img, uint32_t *hist, long long N, int B, long long s
         hipLaunchKernelGGL((hist_kernel<true>), grid, dim3(256), 0, s, img, hist, N, stride);
     else
         hipLaunchKernelGGL((hist_kernel<false>), grid, dim3(256), 0, s, img, hist, N, stride);
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
+int iak_msqe(const uint8_t *in, const uint8_t *out, const uint32_t *hist, uint32_t *sums, long long N, int B,
+             long long in_stride, long long out_stride, void *stream) {
+    if (!in || !out || !hist || !sums || N <= 0 || B <= 0 || in_stride < N || out_stride < N) return IAK_E_ARG;
+    hipStream_t s = as_stream(stream);
+    IAK_HIP(hipMemsetAsync(sums, 0, sizeof(uint32_t) * (size_t)B, s));
+    dim3 grid(blocks_x(N, 256 * 16, B), B);
+    hipLaunchKernelGGL(msqe_kernel, grid, dim3(256), 0, s, in, out, hist, sums, N, in_stride, out_stride);
     IAK_LAUNCH_CHECK();
     return 0;
 }

@@ -13,6 +13,8 @@
 //   * a generic path (any width, any kW x kH up to IAK_MAX_TAPS), one pixel per lane.
 #include "iak_common.hpp"
 
+#include <cstdlib>
+
 namespace iak {
 
 struct Taps {  // by-value kernel argument
@@ -189,53 +191,81 @@ __global__ __launch_bounds__(256) void generic_edge_kernel(const uint8_t *__rest
 // =======================================================================================
 // 3x3 path, W % 16 == 0
 // =======================================================================================
-#define ROWS_PER_LANE 8
 
-struct Row18 {        // pixels col0-1 .. col0+16 of one image row (flat addressing)
+struct Row18 {        // pixels col0-1 .. col0+16 of one image row (flat addressing), packed
     uint32_t c[4];    // col0 .. col0+15
     uint32_t l, r;    // col0-1, col0+16
 };
 
-// J in [-1, 16]
-template <int J>
-__device__ __forceinline__ uint32_t px(const Row18 &q) {
-    if (J < 0) return q.l;
-    if (J > 15) return q.r;
-    return (q.c[(J & 15) >> 2] >> (8 * (J & 3))) & 0xffu;
-}
-
+// Branch-free: the address is clamped into the image and the result zeroed where the flat
+// index falls outside it, so all the loads of a strip can be in flight together.
 __device__ __forceinline__ Row18 load_row(const uint8_t *img, long long N, long long off, bool valid_row) {
     Row18 q;
-    if (valid_row && off < N) {  // N % 16 == 0: a chunk is wholly inside or wholly outside
-        u32x4 v = ld16(img + off);
-        q.c[0] = v[0]; q.c[1] = v[1]; q.c[2] = v[2]; q.c[3] = v[3];
-    } else {
-        q.c[0] = q.c[1] = q.c[2] = q.c[3] = 0;
-    }
-    q.l = (valid_row && off >= 1 && off - 1 < N) ? img[off - 1] : 0u;
-    q.r = (valid_row && off + 16 < N) ? img[off + 16] : 0u;
+    const bool okc = valid_row && off < N;  // N % 16 == 0: a chunk is wholly inside or wholly outside
+    const bool okl = valid_row && off >= 1 && off - 1 < N;
+    const bool okr = valid_row && off + 16 < N;
+    const u32x4 v = ld16(img + (okc ? off : 0));
+    const uint32_t l = img[okl ? off - 1 : 0];
+    const uint32_t r = img[okr ? off + 16 : 0];
+    q.c[0] = okc ? v[0] : 0u; q.c[1] = okc ? v[1] : 0u; q.c[2] = okc ? v[2] : 0u; q.c[3] = okc ? v[3] : 0u;
+    q.l = okl ? l : 0u;
+    q.r = okr ? r : 0u;
     return q;
 }
 
-// Op interface: template<int J> uint32_t at(const Row18& up, const Row18& mid, const Row18& dn) -> 0..255
-// plus `static const bool kBorderZero` (false only for dilation, whose border pixels can
-// be reached by a neighbour's window) and `prep(Row18&, row, col0, W, H)` applied to each
-// loaded row (dilation masks non-source pixels there).
-template <class Op, int J>
-struct Unroll16 {
-    __device__ __forceinline__ static void run(const Op &op, const Row18 &u, const Row18 &m, const Row18 &d,
-                                               uint32_t *o) {
-        Unroll16<Op, J - 1>::run(op, u, m, d, o);
-        o[J >> 2] |= (op.template at<J>(u, m, d) & 0xffu) << (8 * (J & 3));
-    }
-};
-template <class Op>
-struct Unroll16<Op, -1> {
-    __device__ __forceinline__ static void run(const Op &, const Row18 &, const Row18 &, const Row18 &, uint32_t *) {}
-};
+// three-input integer ops are single instructions on gfx950; the asm pins them
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int imed3(int a, int b, int c) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
-template <class Op>
-__global__ __launch_bounds__(256) void stencil3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
+// low bytes of four values -> one packed word, three v_perm_b32 (no masking needed)
+__device__ __forceinline__ uint32_t pack4_lo(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
+    uint32_t p01 = __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u);
+    uint32_t p23 = __builtin_amdgcn_perm(b3, b2, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+}
+
+// A row with one pixel per register: p[i] = pixel col0-1+i, i in [0,18)
+struct URow {
+    uint32_t p[18];
+};
+__device__ __forceinline__ void unpack(const Row18 &q, URow &u) {
+    u.p[0] = q.l;
+    u.p[17] = q.r;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        u.p[1 + 4 * w] = q.c[w] & 0xffu;
+        u.p[2 + 4 * w] = (q.c[w] >> 8) & 0xffu;
+        u.p[3 + 4 * w] = (q.c[w] >> 16) & 0xffu;
+        u.p[4 + 4 * w] = q.c[w] >> 24;
+    }
+}
+
+// Op interface:
+//   typedef ... Row;                         a prepared input row kept in registers
+//   void prepare(const Row18&, row, col0, W, H, Row&)   once per loaded row
+//   void compute(const Row& up, const Row& mid, const Row& dn, uint32_t o[4])   16 outputs
+//   static const bool kBorderZero            false only for dilation (its border pixels can
+//                                            be reached by a neighbour's window)
+template <class Op, int ROWS_PER_LANE, int MIN_WAVES>
+__global__ __launch_bounds__(256, MIN_WAVES) void stencil3_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
                                                        int H, long long in_stride, long long out_stride, Op op) {
     const long long N = (long long)W * H;
     const uint8_t *src = in + (long long)blockIdx.y * in_stride;
@@ -249,207 +279,341 @@ __global__ __launch_bounds__(256) void stencil3_kernel(const uint8_t *__restrict
         const int cx = (int)(it - (long long)strip * chunks);
         const int col0 = cx << 4;
         const int y0 = strip * ROWS_PER_LANE;
-        Row18 up = load_row(src, N, (long long)(y0 - 1) * W + col0, y0 - 1 >= 0);
-        op.prep(up, y0 - 1, col0, W, H);
-        Row18 mid = load_row(src, N, (long long)y0 * W + col0, true);
-        op.prep(mid, y0, col0, W, H);
+        // all rows of the strip (and its two halo rows) are requested before any is used
+        Row18 raw[ROWS_PER_LANE + 2];
+#pragma unroll
+        for (int r = 0; r < ROWS_PER_LANE + 2; r++)
+            raw[r] = load_row(src, N, (long long)(y0 - 1 + r) * W + col0, y0 - 1 + r >= 0);
+        typename Op::Row up, mid, dn;
+        op.prepare(raw[0], y0 - 1, col0, W, H, up);
+        op.prepare(raw[1], y0, col0, W, H, mid);
 #pragma unroll
         for (int r = 0; r < ROWS_PER_LANE; r++) {
             const int row = y0 + r;
-            if (row >= H) break;
-            Row18 dn = load_row(src, N, (long long)(row + 1) * W + col0, true);
-            op.prep(dn, row + 1, col0, W, H);
-            uint32_t o[4] = {0, 0, 0, 0};
-            Unroll16<Op, 15>::run(op, up, mid, dn, o);
+            op.prepare(raw[r + 2], row + 1, col0, W, H, dn);
+            uint32_t o[4];
+            op.compute(up, mid, dn, o);
             if (Op::kBorderZero) {
                 if (row < 1) o[0] = o[1] = o[2] = o[3] = 0;  // row > H-1 cannot happen
                 if (col0 == 0) o[0] &= 0xffffff00u;          // col < 1; col > W-1 cannot happen
             }
             u32x4 v = {o[0], o[1], o[2], o[3]};
-            st16(dst + (long long)row * W + col0, v);
+            if (row < H) st16(dst + (long long)row * W + col0, v);  // straight-line body: loads stay hoisted
             up = mid;
             mid = dn;
         }
     }
 }
 
-// median of three unsigned values: one v_med3_u32
-__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-struct NoPrep {
-    __device__ __forceinline__ void prep(Row18 &, int, int, int, int) const {}
+struct UnpackedRows {
+    typedef URow Row;
+    __device__ __forceinline__ void prepare(const Row18 &q, int, int, int, int, URow &u) const { unpack(q, u); }
 };
 
-// linear / average with float weights: exact restatement of the truncating accumulate
-struct Linear3Float : NoPrep {
+// ---- linear / average, float weights ---------------------------------------------------
+// The reference accumulates `int sum; sum += uchar * float` (imageAnalysis.cu:517-524): the
+// running sum is truncated toward zero after every tap.  For |x| < 2^31, (int)x equals
+// truncf(x), so the sum is kept as an integral float and the int<->float round trips go.
+struct FRow {
+    float f[18];  // f[i] = pixel col0-1+i
+};
+
+template <bool AVERAGE>
+struct Linear3Float {
     static const bool kBorderZero = true;
+    typedef FRow Row;
     float k[9];
-    int average;
-    template <int J>
-    __device__ __forceinline__ uint32_t at(const Row18 &u, const Row18 &m, const Row18 &d) const {
-        // (int)x for |x| < 2^31 equals truncf(x); keeping the running sum as an integral float
-        // skips the int<->float round trips.  Partial sums stay far below 2^24 for sane weights,
-        // where float holds every integer exactly.
-        float sum = 0.0f;
-        sum = truncf(sum + (float)px<J - 1>(u) * k[0]);
-        sum = truncf(sum + (float)px<J>(u) * k[1]);
-        sum = truncf(sum + (float)px<J + 1>(u) * k[2]);
-        sum = truncf(sum + (float)px<J - 1>(m) * k[3]);
-        sum = truncf(sum + (float)px<J>(m) * k[4]);
-        sum = truncf(sum + (float)px<J + 1>(m) * k[5]);
-        sum = truncf(sum + (float)px<J - 1>(d) * k[6]);
-        sum = truncf(sum + (float)px<J>(d) * k[7]);
-        sum = truncf(sum + (float)px<J + 1>(d) * k[8]);
-        int s = (int)sum;
-        if (average) return (uint32_t)(s / 9) & 0xffu;
-        return (uint32_t)(s > 255 ? 255 : (s < 0 ? 0 : s));
+    __device__ __forceinline__ void prepare(const Row18 &q, int, int, int, int, FRow &f) const {
+        f.f[0] = (float)q.l;
+        f.f[17] = (float)q.r;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            f.f[1 + 4 * w] = (float)(q.c[w] & 0xffu);
+            f.f[2 + 4 * w] = (float)((q.c[w] >> 8) & 0xffu);
+            f.f[3 + 4 * w] = (float)((q.c[w] >> 16) & 0xffu);
+            f.f[4 + 4 * w] = (float)(q.c[w] >> 24);
+        }
+    }
+    __device__ __forceinline__ void compute(const FRow &u, const FRow &m, const FRow &d, uint32_t o[4]) const {
+        int res[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            float sum = 0.0f;
+            sum = truncf(sum + u.f[j] * k[0]);
+            sum = truncf(sum + u.f[j + 1] * k[1]);
+            sum = truncf(sum + u.f[j + 2] * k[2]);
+            sum = truncf(sum + m.f[j] * k[3]);
+            sum = truncf(sum + m.f[j + 1] * k[4]);
+            sum = truncf(sum + m.f[j + 2] * k[5]);
+            sum = truncf(sum + d.f[j] * k[6]);
+            sum = truncf(sum + d.f[j + 1] * k[7]);
+            sum = truncf(sum + d.f[j + 2] * k[8]);
+            const int s = (int)sum;
+            res[j] = AVERAGE ? s / 9 : imed3(s, 0, 255);
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+            o[w] = pack4_lo((uint32_t)res[4 * w], (uint32_t)res[4 * w + 1], (uint32_t)res[4 * w + 2],
+                            (uint32_t)res[4 * w + 3]);
     }
 };
 
-// same with integral weights: pure integer arithmetic, identical results
-struct Linear3Int : NoPrep {
+// Non-negative weights that are multiples of 2^-q (box / binomial masks over a power of two):
+// with the sum held as an integer scaled by 2^q, "add the product, truncate" is one 24-bit
+// multiply-add and one AND.  Chosen by the launcher only where every float operation of the
+// path above would have been exact, so the results are identical.
+template <bool AVERAGE>
+struct Linear3Fixed : UnpackedRows {
+    static const bool kBorderZero = true;
+    uint32_t k[9];  // weight * 2^q
+    int q;
+    __device__ __forceinline__ void compute(const URow &u, const URow &m, const URow &d, uint32_t o[4]) const {
+        const uint32_t keep = ~((1u << q) - 1u);
+        int res[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint32_t s = __umul24(u.p[j], k[0]) & keep;
+            s = (s + __umul24(u.p[j + 1], k[1])) & keep;
+            s = (s + __umul24(u.p[j + 2], k[2])) & keep;
+            s = (s + __umul24(m.p[j], k[3])) & keep;
+            s = (s + __umul24(m.p[j + 1], k[4])) & keep;
+            s = (s + __umul24(m.p[j + 2], k[5])) & keep;
+            s = (s + __umul24(d.p[j], k[6])) & keep;
+            s = (s + __umul24(d.p[j + 1], k[7])) & keep;
+            s = (s + __umul24(d.p[j + 2], k[8])) & keep;
+            const int v = (int)(s >> q);
+            res[j] = AVERAGE ? v / 9 : min(v, 255);
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+            o[w] = pack4_lo((uint32_t)res[4 * w], (uint32_t)res[4 * w + 1], (uint32_t)res[4 * w + 2],
+                            (uint32_t)res[4 * w + 3]);
+    }
+};
+
+// same with integral weights (every partial sum exact in float): 24-bit integer multiply-adds
+template <bool AVERAGE>
+struct Linear3Int : UnpackedRows {
     static const bool kBorderZero = true;
     int k[9];
-    int average;
-    template <int J>
-    __device__ __forceinline__ uint32_t at(const Row18 &u, const Row18 &m, const Row18 &d) const {
-        int s = (int)px<J - 1>(u) * k[0] + (int)px<J>(u) * k[1] + (int)px<J + 1>(u) * k[2] +
-                (int)px<J - 1>(m) * k[3] + (int)px<J>(m) * k[4] + (int)px<J + 1>(m) * k[5] +
-                (int)px<J - 1>(d) * k[6] + (int)px<J>(d) * k[7] + (int)px<J + 1>(d) * k[8];
-        if (average) return (uint32_t)(s / 9) & 0xffu;
-        return (uint32_t)(s > 255 ? 255 : (s < 0 ? 0 : s));
+    __device__ __forceinline__ void compute(const URow &u, const URow &m, const URow &d, uint32_t o[4]) const {
+        int res[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            int s = __mul24((int)u.p[j], k[0]);
+            s += __mul24((int)u.p[j + 1], k[1]);
+            s += __mul24((int)u.p[j + 2], k[2]);
+            s += __mul24((int)m.p[j], k[3]);
+            s += __mul24((int)m.p[j + 1], k[4]);
+            s += __mul24((int)m.p[j + 2], k[5]);
+            s += __mul24((int)d.p[j], k[6]);
+            s += __mul24((int)d.p[j + 1], k[7]);
+            s += __mul24((int)d.p[j + 2], k[8]);
+            res[j] = AVERAGE ? s / 9 : imed3(s, 0, 255);
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+            o[w] = pack4_lo((uint32_t)res[4 * w], (uint32_t)res[4 * w + 1], (uint32_t)res[4 * w + 2],
+                            (uint32_t)res[4 * w + 3]);
     }
 };
 
-struct Sobel3 : NoPrep {
+// floor(sqrt(q)) & 255 for 0 <= q <= 2*255^2, as (uchar)sqrtf((float)q) gives it
+// (imageAnalysis.cu:552).  The hardware square root is good to 1 ulp (3e-5 at 360); the
+// true root of a non-square q stays at least 1/(2*361) below the next integer, so adding
+// 0.001 before truncating repairs a perfect square that came out one ulp low and never
+// lifts a non-square over an integer.
+__device__ __forceinline__ uint32_t isqrt_small(uint32_t q) {
+    return (uint32_t)(int)(__builtin_amdgcn_sqrtf((float)q) + 0.001f);
+}
+
+struct Sobel3 : UnpackedRows {
     static const bool kBorderZero = true;
-    template <int J>
-    __device__ __forceinline__ uint32_t at(const Row18 &u, const Row18 &m, const Row18 &d) const {
-        // imageAnalysis.cu:560-561 masks; each response clamped to [0,255] by linearFilter
-        int a = px<J - 1>(u), b = px<J>(u), c = px<J + 1>(u);
-        int e = px<J - 1>(m), f = px<J + 1>(m);
-        int g = px<J - 1>(d), h = px<J>(d), i = px<J + 1>(d);
-        int gx = (c - a) + 2 * (f - e) + (i - g);
-        int gy = (g - a) + 2 * (h - b) + (i - c);
-        gx = gx > 255 ? 255 : (gx < 0 ? 0 : gx);
-        gy = gy > 255 ? 255 : (gy < 0 ? 0 : gy);
-        return f2u8(sqrtf((float)(gx * gx + gy * gy)));  // imageAnalysis.cu:552
+    __device__ __forceinline__ void compute(const URow &u, const URow &m, const URow &d, uint32_t o[4]) const {
+        // imageAnalysis.cu:560-561 masks, separated into column sums shared by neighbours:
+        //   s = up + 2*mid + down, t = down - up;  gx = s[j+1] - s[j-1], gy = t[j-1] + 2 t[j] + t[j+1]
+        int s[18], t[18];
+#pragma unroll
+        for (int i = 0; i < 18; i++) {
+            s[i] = (int)(u.p[i] + 2 * m.p[i] + d.p[i]);
+            t[i] = (int)d.p[i] - (int)u.p[i];
+        }
+        uint32_t res[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            int gx = s[j + 2] - s[j];
+            int gy = t[j] + 2 * t[j + 1] + t[j + 2];
+            gx = imed3(gx, 0, 255);  // each response is clamped by linearFilter before the combine
+            gy = imed3(gy, 0, 255);
+            res[j] = isqrt_small((uint32_t)(__mul24(gx, gx) + __mul24(gy, gy)));
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++) o[w] = pack4_lo(res[4 * w], res[4 * w + 1], res[4 * w + 2], res[4 * w + 3]);
     }
 };
 
-struct Compass3 : NoPrep {
+struct Compass3 : UnpackedRows {
     static const bool kBorderZero = true;
-    template <int J>
-    __device__ __forceinline__ uint32_t at(const Row18 &u, const Row18 &m, const Row18 &d) const {
-        int a = px<J - 1>(u), b = px<J>(u), c = px<J + 1>(u);
-        int e = px<J - 1>(m), f = px<J + 1>(m);
-        int g = px<J - 1>(d), h = px<J>(d), i = px<J + 1>(d);
-        int s0 = (c - a) + 2 * (f - e) + (i - g);
-        int s1 = 2 * (i - a) + (f - b) + (h - e);
-        int s2 = (g - a) + 2 * (h - b) + (i - c);
-        int s3 = 2 * (g - c) + (e - b) + (h - f);
-        // the running sum is carried from mask to mask (imageAnalysis.cu:607-618)
-        int sum = abs(s0);
-        int mx = sum;
-        sum = abs(sum + s1); mx = max(mx, sum);
-        sum = abs(sum + s2); mx = max(mx, sum);
-        sum = abs(sum + s3); mx = max(mx, sum);
-        return (uint32_t)mx & 0xffu;
+    __device__ __forceinline__ void compute(const URow &u, const URow &m, const URow &d, uint32_t o[4]) const {
+        uint32_t res[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            int a = u.p[j], b = u.p[j + 1], c = u.p[j + 2];
+            int e = m.p[j], f = m.p[j + 2];
+            int g = d.p[j], h = d.p[j + 1], i = d.p[j + 2];
+            int s0 = (c - a) + 2 * (f - e) + (i - g);
+            int s1 = 2 * (i - a) + (f - b) + (h - e);
+            int s2 = (g - a) + 2 * (h - b) + (i - c);
+            int s3 = 2 * (g - c) + (e - b) + (h - f);
+            // the running sum is carried from mask to mask (imageAnalysis.cu:607-618)
+            int sum = abs(s0);
+            int mx = sum;
+            sum = abs(sum + s1); mx = max(mx, sum);
+            sum = abs(sum + s2); mx = max(mx, sum);
+            sum = abs(sum + s3); mx = max(mx, sum);
+            res[j] = (uint32_t)mx;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++) o[w] = pack4_lo(res[4 * w], res[4 * w + 1], res[4 * w + 2], res[4 * w + 3]);
     }
 };
 
-// 3x3 median of 9, all weights 1: sort the three columns (shared by neighbouring outputs
-// after inlining), then max of lows / median of mids / min of highs, then their median.
-struct Median3 : NoPrep {
+// 3x3 median, all weights 1: sort each of the 18 columns once (min3 / med3 / max3), then per
+// output the max of the three lows, the median of the three middles, the min of the three
+// highs, and the median of those -- 7 three-input instructions per pixel.
+struct Median3 : UnpackedRows {
     static const bool kBorderZero = true;
-    template <int J>
-    __device__ __forceinline__ void col(const Row18 &u, const Row18 &m, const Row18 &d, uint32_t &lo, uint32_t &md,
-                                        uint32_t &hi) const {
-        uint32_t a = px<J>(u), b = px<J>(m), c = px<J>(d);
-        lo = min(a, min(b, c));
-        hi = max(a, max(b, c));
-        md = umed3(a, b, c);
-    }
-    template <int J>
-    __device__ __forceinline__ uint32_t at(const Row18 &u, const Row18 &m, const Row18 &d) const {
-        uint32_t l0, m0, h0, l1, m1, h1, l2, m2, h2;
-        col<J - 1>(u, m, d, l0, m0, h0);
-        col<J>(u, m, d, l1, m1, h1);
-        col<J + 1>(u, m, d, l2, m2, h2);
-        uint32_t maxlo = max(l0, max(l1, l2));
-        uint32_t minhi = min(h0, min(h1, h2));
-        uint32_t medmd = umed3(m0, m1, m2);
-        return umed3(maxlo, medmd, minhi);
+    __device__ __forceinline__ void compute(const URow &u, const URow &m, const URow &d, uint32_t o[4]) const {
+        uint32_t lo[18], md[18], hi[18];
+#pragma unroll
+        for (int i = 0; i < 18; i++) {
+            lo[i] = umin3(u.p[i], m.p[i], d.p[i]);
+            md[i] = umed3(u.p[i], m.p[i], d.p[i]);
+            hi[i] = umax3(u.p[i], m.p[i], d.p[i]);
+        }
+        uint32_t res[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            res[j] = umed3(umax3(lo[j], lo[j + 1], lo[j + 2]), umed3(md[j], md[j + 1], md[j + 2]),
+                           umin3(hi[j], hi[j + 1], hi[j + 2]));
+#pragma unroll
+        for (int w = 0; w < 4; w++) o[w] = pack4_lo(res[4 * w], res[4 * w + 1], res[4 * w + 2], res[4 * w + 3]);
     }
 };
 
-struct Erode3 : NoPrep {
+// ---- 3x3 morphology on bit masks -----------------------------------------------------------
+// A row is reduced to one bit per pixel (bit i = pixel col0-1+i is non-zero / is a source);
+// a structuring element then costs a handful of shifts and ANDs/ORs for all 16 outputs.
+struct MRow {
+    uint32_t bits;   // 18 bits
+    uint32_t c[4];   // the packed pixels (erosion keeps the grey value)
+};
+
+// bit k of the result = byte k of x is non-zero
+__device__ __forceinline__ uint32_t nonzero4(uint32_t x) {
+    uint32_t t = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x;  // bit 7 of each byte = byte != 0
+    t = (t >> 7) & 0x01010101u;
+    return (t * 0x10204080u) >> 28;
+}
+// 4 bits -> 4 bytes of 0x00 / 0xff
+__device__ __forceinline__ uint32_t spread4(uint32_t bits4) {
+    uint32_t t = (bits4 * 0x00204081u) & 0x01010101u;
+    return (t << 8) - t;
+}
+__device__ __forceinline__ uint32_t row_bits(const Row18 &q) {
+    return (q.l != 0 ? 1u : 0u) | (nonzero4(q.c[0]) << 1) | (nonzero4(q.c[1]) << 5) | (nonzero4(q.c[2]) << 9) |
+           (nonzero4(q.c[3]) << 13) | (q.r != 0 ? (1u << 17) : 0u);
+}
+
+struct Erode3 {
     static const bool kBorderZero = true;
+    typedef MRow Row;
     uint32_t mask;  // bit n set: structuring element n is non-zero
-    template <int J>
-    __device__ __forceinline__ uint32_t at(const Row18 &u, const Row18 &m, const Row18 &d) const {
-        const uint32_t p = px<J>(m);
-        bool ok = p > 0;
-        if (mask & 1u) ok = ok && px<J - 1>(u) != 0;
-        if (mask & 2u) ok = ok && px<J>(u) != 0;
-        if (mask & 4u) ok = ok && px<J + 1>(u) != 0;
-        if (mask & 8u) ok = ok && px<J - 1>(m) != 0;
-        if (mask & 16u) ok = ok && px<J>(m) != 0;
-        if (mask & 32u) ok = ok && px<J + 1>(m) != 0;
-        if (mask & 64u) ok = ok && px<J - 1>(d) != 0;
-        if (mask & 128u) ok = ok && px<J>(d) != 0;
-        if (mask & 256u) ok = ok && px<J + 1>(d) != 0;
-        return ok ? p : 0u;
+    __device__ __forceinline__ void prepare(const Row18 &q, int, int, int, int, MRow &r) const {
+        r.bits = row_bits(q);
+        r.c[0] = q.c[0]; r.c[1] = q.c[1]; r.c[2] = q.c[2]; r.c[3] = q.c[3];
+    }
+    __device__ __forceinline__ void compute(const MRow &u, const MRow &m, const MRow &d, uint32_t o[4]) const {
+        // output j looks at bits j, j+1, j+2 of each row (columns j-1, j, j+1)
+        uint32_t ok = 0xffffu;
+        if (mask & 1u) ok &= u.bits;
+        if (mask & 2u) ok &= u.bits >> 1;
+        if (mask & 4u) ok &= u.bits >> 2;
+        if (mask & 8u) ok &= m.bits;
+        if (mask & 16u) ok &= m.bits >> 1;
+        if (mask & 32u) ok &= m.bits >> 2;
+        if (mask & 64u) ok &= d.bits;
+        if (mask & 128u) ok &= d.bits >> 1;
+        if (mask & 256u) ok &= d.bits >> 2;
+        // a zero pixel stays zero whatever ok says: the AND with the pixel itself does it
+#pragma unroll
+        for (int w = 0; w < 4; w++) o[w] = m.c[w] & spread4((ok >> (4 * w)) & 0xfu);
     }
 };
 
 struct Dilate3 {
     static const bool kBorderZero = false;
+    typedef MRow Row;
     uint32_t mask;
-    // Keep only pixels that scatter in the reference: foreground and not on the border
-    // (row >= 1, col >= 1 for a 3x3 window).  The left halo byte of chunk 0 is the previous
-    // row's last pixel, the right halo byte of the last chunk the next row's first.
-    __device__ __forceinline__ void prep(Row18 &q, int row, int col0, int W, int H) const {
-        (void)H;
-        if (row < 1) q.c[0] = q.c[1] = q.c[2] = q.c[3] = 0;
+    // Source pixels are those that scatter in the reference: foreground and not on the border
+    // (row >= 1, col >= 1 for a 3x3 window).  The left halo bit of chunk 0 is the previous
+    // row's last pixel, the right halo bit of the last chunk the next row's first.
+    __device__ __forceinline__ void prepare(const Row18 &q, int row, int col0, int W, int, MRow &r) const {
+        uint32_t b = row_bits(q);
+        if (row < 1) b = 0;
         if (col0 == 0) {
-            q.c[0] &= 0xffffff00u;
-            if (row - 1 < 1) q.l = 0;
-        } else if (row < 1) {
-            q.l = 0;
+            b &= ~2u;                  // column 0
+            if (row - 1 < 1) b &= ~1u;  // left halo = (row-1, W-1)
         }
-        if (col0 + 16 >= W || row < 1) q.r = 0;
+        if (col0 + 16 >= W) b &= ~(1u << 17);  // right halo = (row+1, 0): column 0
+        r.bits = b;
     }
-    template <int J>
-    __device__ __forceinline__ uint32_t at(const Row18 &u, const Row18 &m, const Row18 &d) const {
+    __device__ __forceinline__ void compute(const MRow &u, const MRow &m, const MRow &d, uint32_t o[4]) const {
         // output x takes element n=(di+1)*3+(dj+1) from source x-(di,dj): the window is mirrored
-        bool hit = false;
-        if (mask & 1u) hit = hit || px<J + 1>(d) != 0;    // di=-1,dj=-1 -> source (row+1, col+1)
-        if (mask & 2u) hit = hit || px<J>(d) != 0;        // di=-1,dj=0
-        if (mask & 4u) hit = hit || px<J - 1>(d) != 0;    // di=-1,dj=+1
-        if (mask & 8u) hit = hit || px<J + 1>(m) != 0;    // di=0,dj=-1
-        if (mask & 16u) hit = hit || px<J>(m) != 0;
-        if (mask & 32u) hit = hit || px<J - 1>(m) != 0;
-        if (mask & 64u) hit = hit || px<J + 1>(u) != 0;   // di=+1,dj=-1 -> source (row-1, col+1)
-        if (mask & 128u) hit = hit || px<J>(u) != 0;
-        if (mask & 256u) hit = hit || px<J - 1>(u) != 0;
-        return hit ? 255u : 0u;
+        uint32_t hit = 0;
+        if (mask & 1u) hit |= d.bits >> 2;    // di=-1,dj=-1 -> source (row+1, col+1)
+        if (mask & 2u) hit |= d.bits >> 1;
+        if (mask & 4u) hit |= d.bits;
+        if (mask & 8u) hit |= m.bits >> 2;
+        if (mask & 16u) hit |= m.bits >> 1;
+        if (mask & 32u) hit |= m.bits;
+        if (mask & 64u) hit |= u.bits >> 2;   // di=+1,dj=-1 -> source (row-1, col+1)
+        if (mask & 128u) hit |= u.bits >> 1;
+        if (mask & 256u) hit |= u.bits;
+#pragma unroll
+        for (int w = 0; w < 4; w++) o[w] = spread4((hit >> (4 * w)) & 0xfu);
     }
 };
+
+template <class Op, int RPL, int MINW>
+static int launch3v(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
+                    const Op &op, void *stream) {
+    const long long items = (long long)(W >> 4) * ((H + RPL - 1) / RPL);
+    dim3 grid(blocks_x(items, 256, B, 1 << 20), B);
+    hipLaunchKernelGGL((stencil3_kernel<Op, RPL, MINW>), grid, dim3(256), 0, as_stream(stream), in, out, W, H,
+                       in_stride, out_stride, op);
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
 
 template <class Op>
 static int launch3(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
                    const Op &op, void *stream) {
-    const long long items = (long long)(W >> 4) * ((H + ROWS_PER_LANE - 1) / ROWS_PER_LANE);
-    dim3 grid(blocks_x(items, 256, B, 8192), B);
-    hipLaunchKernelGGL((stencil3_kernel<Op>), grid, dim3(256), 0, as_stream(stream), in, out, W, H, in_stride,
-                       out_stride, op);
-    IAK_LAUNCH_CHECK();
-    return 0;
+    static int variant = -1;
+    if (variant < 0) {
+        const char *e = getenv("IAK_STENCIL_VARIANT");
+        variant = e ? atoi(e) : 0;
+    }
+    switch (variant) {
+    case 1: return launch3v<Op, 8, 4>(in, out, W, H, B, in_stride, out_stride, op, stream);
+    case 2: return launch3v<Op, 8, 6>(in, out, W, H, B, in_stride, out_stride, op, stream);
+    case 3: return launch3v<Op, 4, 1>(in, out, W, H, B, in_stride, out_stride, op, stream);
+    case 4: return launch3v<Op, 4, 6>(in, out, W, H, B, in_stride, out_stride, op, stream);
+    case 5: return launch3v<Op, 16, 1>(in, out, W, H, B, in_stride, out_stride, op, stream);
+    case 6: return launch3v<Op, 16, 4>(in, out, W, H, B, in_stride, out_stride, op, stream);
+    case 7: return launch3v<Op, 4, 8>(in, out, W, H, B, in_stride, out_stride, op, stream);
+    default: return launch3v<Op, 8, 1>(in, out, W, H, B, in_stride, out_stride, op, stream);
+    }
 }
 
 static bool fast3_ok(const uint8_t *in, const uint8_t *out, int W, long long in_stride, long long out_stride) {
@@ -487,15 +651,57 @@ int iak_linear(const uint8_t *in, uint8_t *out, int W, int H, int B, long long i
             integral = integral && (kernel[i] == (float)(int)kernel[i]) && kernel[i] > -65536.f && kernel[i] < 65536.f;
             mag += 255.0 * (kernel[i] < 0 ? -kernel[i] : kernel[i]);
         }
-        if (integral && mag < 16777216.0) {  // every partial sum exact in float: integer path is identical
-            Linear3Int op;
-            for (int i = 0; i < 9; i++) op.k[i] = (int)kernel[i];
-            op.average = (mode == IAK_LINEAR_AVERAGE);
+        const bool avg = (mode == IAK_LINEAR_AVERAGE);
+        if (integral && mag < 8388608.0) {  // every partial sum exact in float and within 24 bits
+            int ik[9];
+            for (int i = 0; i < 9; i++) ik[i] = (int)kernel[i];
+            if (avg) {
+                Linear3Int<true> op;
+                for (int i = 0; i < 9; i++) op.k[i] = ik[i];
+                return launch3(in, out, W, H, B, in_stride, out_stride, op, stream);
+            }
+            Linear3Int<false> op;
+            for (int i = 0; i < 9; i++) op.k[i] = ik[i];
             return launch3(in, out, W, H, B, in_stride, out_stride, op, stream);
         }
-        Linear3Float op;
+        // fixed-point path: weights >= 0, all multiples of 2^-q (q <= 12), and every partial sum
+        // (< 255 * sum of weights) needs no more than 24 bits including the q fraction bits
+        {
+            bool ok = true;
+            int q = 0;
+            double total = 0;
+            for (int i = 0; i < 9 && ok; i++) {
+                const float w = kernel[i];
+                if (!(w >= 0.0f) || w > 4096.0f) { ok = false; break; }
+                total += w;
+                int qi = 0;
+                float t = w;
+                while (t != (float)(int)t && qi <= 12) { t *= 2.0f; qi++; }
+                if (qi > 12) ok = false;
+                if (qi > q) q = qi;
+            }
+            if (ok && q > 0 && total * 255.0 * (double)(1 << q) < 16777216.0) {
+                uint32_t fk[9];
+                for (int i = 0; i < 9; i++) fk[i] = (uint32_t)(kernel[i] * (float)(1 << q));
+                if (avg) {
+                    Linear3Fixed<true> op;
+                    for (int i = 0; i < 9; i++) op.k[i] = fk[i];
+                    op.q = q;
+                    return launch3(in, out, W, H, B, in_stride, out_stride, op, stream);
+                }
+                Linear3Fixed<false> op;
+                for (int i = 0; i < 9; i++) op.k[i] = fk[i];
+                op.q = q;
+                return launch3(in, out, W, H, B, in_stride, out_stride, op, stream);
+            }
+        }
+        if (avg) {
+            Linear3Float<true> op;
+            for (int i = 0; i < 9; i++) op.k[i] = kernel[i];
+            return launch3(in, out, W, H, B, in_stride, out_stride, op, stream);
+        }
+        Linear3Float<false> op;
         for (int i = 0; i < 9; i++) op.k[i] = kernel[i];
-        op.average = (mode == IAK_LINEAR_AVERAGE);
         return launch3(in, out, W, H, B, in_stride, out_stride, op, stream);
     }
     // taps actually visited are (2a+1) x (2s+1), indexed consecutively (imageAnalysis.cu:518-523)

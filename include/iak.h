@@ -93,6 +93,14 @@ int iak_otsu_threshold(const uint32_t *hist, int32_t *thr, int numPixels, int B,
  * exact (the reference's float tree sum has no defined order). */
 int iak_mean_std(const uint32_t *hist, float *mean_std, int numPixels, int B, void *stream);
 
+/* The per-pixel part of calcMSQE (imageAnalysis.cu:780-812): for every image
+ * sums[b] = sum_t (uchar)round((in-out)^2 * (hist[in]/255.0)), with hist the histogram of
+ * `in` as iak_hist gives it (DEVICE [B][256]).  The reference then adds the bytes with
+ * plus<unsigned char>, i.e. modulo 256 -- the caller applies that.  (The reference reads its
+ * histogram from a buffer it never fills; the intended histogram is used here.) */
+int iak_msqe(const uint8_t *in, const uint8_t *out, const uint32_t *hist, uint32_t *sums, long long N, int B,
+             long long in_stride, long long out_stride, void *stream);
+
 /* ---- random numbers --------------------------------------------------------------------
  * Replaces setupRandomness + setup_kernel (imageAnalysis.cu:709-715,740-746).
  * curand_init(seed, tid, 0) followed by two curand() draws, for tid in [0,N): the only

@@ -214,6 +214,9 @@ KERNELS3 = {
     "gauss16": [1 / 16, 2 / 16, 1 / 16, 2 / 16, 4 / 16, 2 / 16, 1 / 16, 2 / 16, 1 / 16],
     "sharpen": [0, -1, 0, -1, 5, -1, 0, -1, 0],
     "odd": [0.3, -0.7, 1.9, 0.01, 2.5, -1.3, 0.77, 0.2, -0.45],
+    "dyadic": [0.5, 0.25, 0, 0.125, 1, 2, 0.0625, 0, 0.5],
+    "dyadic-big": [3.5, 0.25, 7, 0.125, 1, 2, 0.0625, 9, 0.5],
+    "fine": [1 / 4096, 0, 0, 0, 1 / 2, 0, 0, 0, 1 / 8192],
 }
 
 

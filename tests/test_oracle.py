@@ -1,0 +1,300 @@
+"""CPU checks of the oracle itself: known-answer vectors derived by hand from the reference
+source text, self-consistency of the XORWOW restatement, and properties the reference's
+races leave open.  No GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+
+
+def test_gray_known_answers():
+    # imageAnalysis.cu:22 in double, truncated: white is 254, not 255
+    def g(r, gg, b):
+        return int(O.gray(np.array([[[r]], [[gg]], [[b]]], np.uint8))[0, 0])
+    assert g(255, 255, 255) == 254
+    assert g(10, 20, 30) == 18
+    assert g(200, 100, 50) == 117
+    assert g(100, 150, 200) == 143
+    assert g(0, 0, 0) == 0
+    assert int(O.gray(np.array([[[10]], [[20]], [[31]]], np.uint8), 1)[0, 0]) == 20  # (10+20+31)/3
+    assert O.gray(np.zeros((3, 2, 2), np.uint8), 7) is None
+
+
+def test_gray_matches_exact_rational_except_multiples_of_100():
+    rs = np.random.default_rng(1)
+    rgb = rs.integers(0, 256, size=(3, 64, 64), dtype=np.uint8)
+    got = O.gray(rgb).astype(np.int64)
+    r64 = rgb.astype(np.int64)
+    s = 21 * r64[0] + 72 * r64[1] + 7 * r64[2]
+    exact = s // 100
+    off = got != exact
+    assert (s[off] % 100 == 0).all() and (exact[off] - got[off] == 1).all()
+
+
+def test_histogram_skips_zero():
+    img = np.array([[0, 0, 1, 1], [255, 7, 7, 7]], np.uint8)
+    h = O.hist(img)
+    assert h[0] == 0 and h[1] == 2 and h[7] == 3 and h[255] == 1 and h.sum() == 6
+
+
+def test_equalization_map_known_answer():
+    h = np.zeros(256, np.int32)
+    h[10], h[20], h[200] = 4, 4, 8
+    m = O.eq_map(h, 16)
+    assert m[9] == 0 and (m[10:20] == 63).all() and (m[20:200] == 127).all() and (m[200:] == 255).all()
+
+
+def test_equalization_zero_pixels_keep_top_below_255():
+    img = np.zeros((4, 4), np.uint8)
+    img[0, :] = 9
+    m = O.eq_map(O.hist(img), 16)
+    assert m[255] == int(np.float32(4) / np.float32(16) * 255)  # the zeros are never counted
+
+
+def test_quantization_first_match_wins_and_identity():
+    img = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    out = O.quantize(img, [[10, 20, 15], [15, 30, 99], [40, 256, 300]])
+    assert (out[0, 10:16] == 15).all() and out[1, 3] == 15 and (out.ravel()[20:30] == 99).all()
+    assert (out.ravel()[30:40] == np.arange(30, 40)).all()
+    assert (out.ravel()[40:] == (300 & 0xff)).all()
+    assert np.array_equal(O.quantize(img, []), img)
+
+
+def test_threshold_and_otsu():
+    img = np.array([[0, 40, 41, 255]], np.uint8)
+    assert O.threshold(img, 40).tolist() == [[0, 0, 255, 255]]
+    two = np.array([[50] * 8 + [200] * 8], np.uint8)
+    out, thr = O.otsu(two)
+    assert thr == 50 and out.tolist() == [[0] * 8 + [255] * 8]
+
+
+def test_mean_std_known_answer():
+    img = np.array([[1, 2, 3, 4]], np.uint8)
+    m, s = O.mean_std(img)
+    assert m == np.float32(2.5)
+    assert s == np.sqrt(np.float32(np.float32(5.0) / np.float32(3)))
+
+
+# ---- XORWOW ---------------------------------------------------------------------------------
+
+def _step(v):
+    t = (v[0] ^ (v[0] >> 2)) & 0xffffffff
+    v = v[1:] + [((v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1))) & 0xffffffff]
+    return v
+
+
+def _matvec(m, v):
+    r = [0] * 5
+    for i in range(5):
+        for j in range(32):
+            if v[i] >> j & 1:
+                for k in range(5):
+                    r[k] ^= int(m[(i * 32 + j) * 5 + k])
+    return r
+
+
+def test_xorwow_jump_matrix_equals_stepping():
+    rs = np.random.default_rng(3)
+    for log2 in (0, 1, 5, 10):
+        m = O.jump_matrix(log2)
+        v = [int(x) for x in rs.integers(0, 2 ** 32, size=5, dtype=np.uint64)]
+        w = list(v)
+        for _ in range(1 << log2):
+            w = _step(w)
+        assert _matvec(m, v) == w
+
+
+def test_xorwow_stream_python_model():
+    # independent Python restatement of seeding + stepping for subsequence 0
+    seed = 1234
+    s0 = (seed & 0xffffffff) ^ 0xaad26b49
+    s1 = (seed >> 32) ^ 0xf7dcefdd
+    t0 = (1099087573 * s0) & 0xffffffff
+    t1 = (2591861531 * s1) & 0xffffffff
+    d = (6615241 + t1 + t0) & 0xffffffff
+    v = [(123456789 + t0) & 0xffffffff, 362436069 ^ t0, (521288629 + t1) & 0xffffffff, 88675123 ^ t1,
+         (5783321 + t0) & 0xffffffff]
+    want = []
+    for _ in range(6):
+        v = _step(v)
+        d = (d + 362437) & 0xffffffff
+        want.append((v[4] + d) & 0xffffffff)
+    assert O.xorwow_stream(seed, 0, 6).tolist() == want
+
+
+def test_xorwow_subsequences_are_2_pow_67_apart():
+    # subsequence a+b == jump(a) then jump(b): check 3 = 1 then 2 through the matrices
+    j0, j1 = O.jump_matrix(67), O.jump_matrix(68)
+    s3 = O.xorwow_stream(1234, 3, 1)[0]
+    seed = 1234
+    s0 = (seed & 0xffffffff) ^ 0xaad26b49
+    t0 = (1099087573 * s0) & 0xffffffff
+    t1 = (2591861531 * (0 ^ 0xf7dcefdd)) & 0xffffffff
+    d = (6615241 + t1 + t0) & 0xffffffff
+    v = [(123456789 + t0) & 0xffffffff, 362436069 ^ t0, (521288629 + t1) & 0xffffffff, 88675123 ^ t1,
+         (5783321 + t0) & 0xffffffff]
+    v = _matvec(j1, _matvec(j0, v))
+    v = _step(v)
+    assert s3 == (v[4] + d + 362437) & 0xffffffff
+
+
+def test_xorwow_jump_matches_rocrand_tables():
+    """rocRAND ships precomputed 2^67-step and 1-step matrices of the same published
+    recurrence; they are an independent derivation of the jump used by curand_init."""
+    path = "/opt/rocm/include/rocrand/rocrand_xorwow_precomputed.h"
+    if not os.path.exists(path):
+        pytest.skip("rocRAND headers not installed")
+    txt = open(path).read()
+
+    def first_matrix(symbol):
+        i = txt.index(symbol)
+        j = txt.index("{", i)
+        nums = re.findall(r"0x[0-9a-fA-F]+|\d+", txt[j:j + 20000])[:800]
+        return np.array([int(x, 0) for x in nums], dtype=np.uint64).astype(np.uint32)
+
+    assert np.array_equal(O.jump_matrix(67), first_matrix("h_xorwow_sequence_jump_matrices"))
+    assert np.array_equal(O.jump_matrix(0), first_matrix("h_xorwow_jump_matrices"))
+
+
+def test_uniform_range():
+    assert O.lib().iao_uniform(0) == np.float32(2.3283064e-10) / np.float32(2)
+    assert O.lib().iao_uniform(0xffffffff) == 1.0
+
+
+# ---- noise ------------------------------------------------------------------------------------
+
+def test_salt_pepper_rate_and_values():
+    W, H = 256, 128
+    x0, x1 = O.xorwow_planes(W * H)
+    img = np.full((H, W), 77, np.uint8)
+    out = O.salt_pepper(img, x0, x1, 50)
+    changed = out != 77
+    assert abs(changed.mean() - (1 - 50 / 50.999999)) < 0.004
+    assert set(np.unique(out[changed])) <= {0, 255}
+    # the same field every call (states are never written back, imageAnalysis.cu:723)
+    assert np.array_equal(out, O.salt_pepper(img, x0, x1, 50))
+    # level 0: every draw is "noise"
+    assert set(np.unique(O.salt_pepper(img, x0, x1, 0))) <= {0, 255}
+
+
+def test_gauss_table_portable_exp_vs_libm():
+    rs = np.random.default_rng(4)
+    diffs = total = 0
+    for _ in range(300):
+        mean = np.float32(rs.uniform(0, 255))
+        var = np.float32(rs.uniform(0.5, 90) ** 2)
+        a, b = O.gauss_table(mean, var, False), O.gauss_table(mean, var, True)
+        diffs += int((a != b).sum())
+        total += 256
+        assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+    assert diffs <= total * 1e-3  # only exact rounding ties can differ
+    t = O.gauss_table(100.0, 25.0)
+    assert t[100] == 255 and t[0] == 0 and t[99] == round(255 * np.exp(-1 / 50.0))
+
+
+def test_gauss_noise_degenerate_variance():
+    W, H = 64, 8
+    x0, _ = O.xorwow_planes(W * H)
+    img = np.full((H, W), 9, np.uint8)  # variance 0: exp(-inf) = 0 everywhere but rv == mean (NaN -> 0)
+    out = O.gauss_noise(img, x0, -1, -1)
+    rv = (np.array([O.lib().iao_uniform(int(x)) for x in x0], np.float64) * 255.999999).astype(int).reshape(H, W)
+    assert (out[rv != 9] == 9).all() and (out[rv == 9] == 0).all()
+
+
+# ---- stencils -----------------------------------------------------------------------------------
+
+def test_linear_constant_image_and_border():
+    W, H, c = 12, 9, 7
+    img = np.full((H, W), c, np.uint8)
+    k = [1, 1, 1, 10, 1, 1, 1, 1, 1]
+    out = O.linear(img, k, 3, 3)
+    assert (out[0] == 0).all() and (out[:, 0] == 0).all()          # top row, left column: border
+    assert (out[1:H - 2, 1:W] == 18 * c).all()                       # last column is interior (wraps)
+    assert (out[H - 2, 1:W - 1] == 18 * c).all()
+    assert out[H - 2, W - 1] == 17 * c                               # its (H-1, W) tap is flat index W*H: 0
+    assert (out[H - 1, 1:W - 1] == 15 * c).all()                     # bottom row reads 3 zero taps
+    assert out[H - 1, W - 1] == 14 * c
+    avg = O.average(img, k, 3, 3)
+    assert (avg[1:H - 2, 1:W] == (18 * c) // 9).all()
+    assert (O.linear(np.full((H, W), 200, np.uint8), k, 3, 3)[1:, 1:] == 255).all()  # clamp
+
+
+def test_linear_truncates_every_tap():
+    img = np.full((3, 3), 3, np.uint8)
+    # 9 taps of 0.4*3 = 1.2 -> each adds 1 after truncation, not int(10.8)
+    assert O.linear(img, [0.4] * 9, 3, 3)[1, 1] == 9
+    # right column wraps to the next row's first pixel
+    w = np.zeros((3, 4), np.uint8)
+    w[2, 0] = 100
+    assert O.linear(w, [0, 0, 0, 0, 0, 1, 0, 0, 0], 3, 3)[1, 3] == 100
+
+
+def test_sobel_compass_median_erosion_known_answers():
+    flat = np.full((8, 16), 50, np.uint8)
+    assert (O.sobel(flat)[1:7, 1:16] == 0).all()
+    assert (O.median(flat, [1] * 9, 3, 3)[1:, 1:] == 50).all()      # bottom row: {0,0,0,50 x6} -> 50
+    g = np.full((5, 5), 90, np.uint8)
+    e = O.erode(g, [0, 1, 0, 1, 1, 1, 0, 1, 0], 3, 3)
+    assert e[2, 2] == 90 and e[0, 0] == 0                            # erosion keeps the grey level
+    assert O.compass(flat)[3, 3] == 0
+
+
+def test_sobel_step_value():
+    step = np.zeros((8, 16), np.uint8)
+    step[:, 8:] = 100
+    # gx = 400 clamps to 255 in the X pass, gy = 0: sqrt(255^2) = 255
+    s = O.sobel(step)
+    assert s[3, 8] == 255 and s[3, 7] == 255 and s[3, 5] == 0
+    # a falling edge has a negative X response, which the clamp of the X pass discards
+    assert O.sobel(step[:, ::-1].copy())[3, 8] == 0
+    # both responses saturated: sqrt(2*255^2) = 360 wraps to 104 in the byte
+    corner = np.zeros((8, 16), np.uint8)
+    corner[4:, 8:] = 255
+    assert O.sobel(corner)[4, 8] == (int(np.sqrt(2 * 255 * 255)) & 0xff)
+
+
+def test_dilation_race_resolutions():
+    rs = np.random.default_rng(6)
+    for (W, H) in [(16, 9), (7, 5), (33, 4)]:
+        img = (rs.random((H, W)) < 0.2).astype(np.uint8) * rs.integers(1, 256, size=(H, W), dtype=np.uint8)
+        for se in ([1] * 9, [0, 1, 0, 1, 1, 1, 0, 1, 0], [1, 0, 0, 0, 0, 0, 0, 0, 1]):
+            a, b = O.dilate(img, se, 3, 3), O.dilate_seq(img, se, 3, 3)
+            assert (b <= a).all()                     # the sequential outcome never exceeds "255 wins"
+            assert set(np.unique(a)) <= {0, 255}
+    one = np.zeros((5, 6), np.uint8)
+    one[2, 3] = 9
+    d = O.dilate(one, [1] * 9, 3, 3)
+    assert (d[1:4, 2:5] == 255).all() and d.sum() == 9 * 255
+    # a foreground pixel on the border row does not scatter
+    top = np.zeros((5, 6), np.uint8)
+    top[0, 3] = 9
+    assert O.dilate(top, [1] * 9, 3, 3).sum() == 0
+
+
+def test_kmeans_and_features_run():
+    img = synth.gray_image("C", 64, 48)
+    out, it = O.kmeans2(img, 215, 101)
+    assert set(np.unique(out)) <= {0, 255} and 1 <= it <= 100
+    f = O.features(img)
+    assert f.shape == (7,) and f[5] <= f[4] <= f[6]
+
+
+def test_pipeline_equals_op_by_op():
+    W, H = 48, 20
+    rgb = synth.rgb_batch("C", W, H, 2)
+    x0, x1 = O.xorwow_planes(W * H)
+    ops = [{"type": O.OP_EQUALIZE}, {"type": O.OP_GAUSS, "mean": -1.0, "stddev": -1.0},
+           {"type": O.OP_SALT_PEPPER, "iparam": 50},
+           {"type": O.OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": [1] * 9}, {"type": O.OP_SOBEL}]
+    out, hs = O.pipeline(rgb, ops, x0, x1, threads=2)
+    total = np.zeros(256, np.int64)
+    for b in range(2):
+        g = O.gray(rgb[b])
+        total += O.hist(g)
+        y = O.sobel(O.median(O.salt_pepper(O.gauss_noise(O.equalize(g), x0), x0, x1, 50), [1] * 9, 3, 3))
+        assert np.array_equal(out[b], y)
+    assert np.array_equal(hs, total)
