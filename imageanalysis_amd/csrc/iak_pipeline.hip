@@ -35,14 +35,44 @@ struct ChainDesc {
     uint8_t const_lut[2][256];  // at most two constant tables per chain
 };
 
-// Per image (one workgroup of 256 lanes): walk the chain once on the histogram, producing
-// every stage's table.  tables: [B][CHAIN_MAX][256] uint16 (LUT stages use the low byte).
+// block-wide helpers for 256 lanes (4 waves)
+__device__ __forceinline__ long long block_sum_ll(long long v, long long *scratch4) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return scratch4[0] + scratch4[1] + scratch4[2] + scratch4[3];
+}
+
+// inclusive prefix sum over the 256 lanes, wrapping 32-bit arithmetic (as `int` in the reference)
+__device__ __forceinline__ int block_scan_i32(int v, int *buf) {
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        int t = (threadIdx.x >= (unsigned)o) ? buf[threadIdx.x - o] : 0;
+        __syncthreads();
+        buf[threadIdx.x] = (int)((unsigned)buf[threadIdx.x] + (unsigned)t);
+        __syncthreads();
+    }
+    return buf[threadIdx.x];
+}
+
+// Per image (one workgroup of 256 lanes, lane v = grey value v): walk the chain once on the
+// histogram, producing every stage's table.  tables: [B][CHAIN_MAX][256] uint16 (LUT stages
+// use the low byte).  Everything that is order-free is done across lanes; the two float
+// accumulations whose order the reference fixes (the cdf, the variance sum) are added up by
+// one lane in bin order from per-lane terms.
 __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *__restrict__ hist_in, int numPixels,
                                                          ChainDesc d, uint16_t *__restrict__ tables) {
-    __shared__ uint32_t h[256];    // current histogram, bin 0 empty
+    __shared__ uint32_t h[256];  // current histogram, bin 0 empty
     __shared__ uint32_t h2[256];
-    __shared__ int32_t map[256];
+    __shared__ float pdf[256];
+    __shared__ double term[256];
+    __shared__ int ibuf[256];
+    __shared__ int ibuf2[256];
+    __shared__ long long red[4];
     __shared__ float ms[2];
+    __shared__ int thr_s;
     const int b = blockIdx.x;
     const int v = threadIdx.x;
     h[v] = hist_in ? hist_in[(long long)b * 256 + v] : 0u;
@@ -50,40 +80,89 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *__restr
     uint16_t *tb = tables + (long long)b * CHAIN_MAX * 256;
     for (int s = 0; s < d.n; s++) {
         const ChainStage st = d.st[s];
+        if (st.type == C_SP) continue;
+        const uint32_t hv = (v == 0) ? 0u : h[v];
         if (st.type == C_GAUSS) {
-            if (v == 0) {
-                float mean = st.mean, sd = st.stddev;
-                if (mean == -1 || sd == -1) mean_std_from_hist(h, numPixels, &mean, &sd);
-                ms[0] = mean;
-                ms[1] = sd * sd;
+            if (st.mean == -1 || st.stddev == -1) {
+                // calculateMeanAndStdDev (imageAnalysis.cu:106-128) from the zero-less histogram
+                const long long sum = block_sum_ll((long long)hv * v, red);
+                const long long nonzero = block_sum_ll((long long)hv, red);
+                const float m = (float)sum / (float)numPixels;
+                const double dv = (double)((float)v - m);
+                const long long c = (v == 0) ? ((long long)numPixels - nonzero) : (long long)hv;
+                term[v] = (double)c * (dv * dv);
+                __syncthreads();
+                if (v == 0) {
+                    double acc = 0.0;
+                    for (int i = 0; i < 256; i++) acc += term[i];
+                    const float variance = (float)acc / (float)((long long)numPixels - 1);
+                    const float sd = sqrtf(variance);
+                    ms[0] = m;
+                    ms[1] = sd * sd;  // imageAnalysis.cu:861 passes stdDev * stdDev
+                }
+            } else if (v == 0) {
+                ms[0] = st.mean;
+                ms[1] = st.stddev * st.stddev;
             }
             __syncthreads();
             tb[s * 256 + v] = gauss_entry(v, ms[0], ms[1]);
             __syncthreads();
             continue;  // position-dependent from here on: the planner never asks for h again
         }
-        if (st.type == C_SP) continue;
         // look-up stages: build the table, then push the histogram through it
-        if (st.type == C_EQUALIZE) {
-            if (v == 0) eq_map_from_hist(h, map, numPixels);
-        } else if (st.type == C_OTSU) {
-            if (v == 0) map[0] = otsu_threshold_from_hist(h, numPixels);
-        }
-        __syncthreads();
         uint32_t lut;
-        if (st.type == C_EQUALIZE) lut = (uint32_t)map[v] & 0xffu;
-        else if (st.type == C_OTSU) lut = (v > map[0]) ? 255u : 0u;
-        else lut = d.const_lut[st.lut_slot][v];
+        if (st.type == C_EQUALIZE) {
+            // equalizeHistogram (imageAnalysis.cu:155-176): divisions in parallel, the float32
+            // running sum strictly in bin order
+            pdf[v] = (float)(int)hv / (float)numPixels;
+            __syncthreads();
+            if (v == 0) {
+                float cdf = 0.0f;
+                for (int i = 0; i < 256; i++) {
+                    cdf = (i > 0) ? (pdf[i] + cdf) : pdf[i];
+                    pdf[i] = cdf;
+                }
+            }
+            __syncthreads();
+            lut = (uint32_t)(int)(pdf[v] * 255) & 0xffu;
+        } else if (st.type == C_OTSU) {
+            // Otsu's loop (imageAnalysis.cu:255-277): running sums by prefix scan, the
+            // between-class variance per lane, then the first bin that attains the maximum
+            const long long sum64 = block_sum_ll((long long)hv * v, red);
+            const int sum = (int)sum64;
+            const int nB = block_scan_i32((int)hv, ibuf);
+            const int bSum = block_scan_i32((int)((unsigned)v * hv), ibuf2);
+            const int nF = numPixels - nB;
+            float bcv = -1.0f;
+            if (nB != 0 && nF != 0) {
+                const float bMean = (float)(bSum / nB);
+                const float fMean = (float)((sum - bSum) / nF);
+                bcv = (float)nB * (float)nF * (bMean - fMean) * (bMean - fMean);
+            }
+            __syncthreads();
+            pdf[v] = bcv;
+            __syncthreads();
+            if (v == 0) {
+                float varMax = 0;
+                int t = 0;
+                for (int i = 0; i < 256; i++)
+                    if (pdf[i] > varMax) {
+                        varMax = pdf[i];
+                        t = i;
+                    }
+                thr_s = t;
+            }
+            __syncthreads();
+            lut = (v > thr_s) ? 255u : 0u;
+        } else {
+            lut = d.const_lut[st.lut_slot][v];
+        }
         tb[s * 256 + v] = (uint16_t)lut;
         h2[v] = 0;
-        __syncthreads();
         // zeros are not in h: bin 0 holds numPixels - sum(others)
-        uint32_t cnt = h[v];
-        if (v == 0) {
-            uint32_t nz = 0;
-            for (int i = 1; i < 256; i++) nz += h[i];
-            cnt = (uint32_t)numPixels - nz;
-        }
+        const long long nonzero = block_sum_ll((long long)hv, red);
+        const uint32_t cnt = (v == 0) ? (uint32_t)((long long)numPixels - nonzero) : hv;
+        __syncthreads();
         if (cnt) atomicAdd(&h2[lut], cnt);
         __syncthreads();
         h[v] = (v == 0) ? 0u : h2[v];

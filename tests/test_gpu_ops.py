@@ -217,6 +217,12 @@ KERNELS3 = {
     "dyadic": [0.5, 0.25, 0, 0.125, 1, 2, 0.0625, 0, 0.5],
     "dyadic-big": [3.5, 0.25, 7, 0.125, 1, 2, 0.0625, 9, 0.5],
     "fine": [1 / 4096, 0, 0, 0, 1 / 2, 0, 0, 0, 1 / 8192],
+    "box16": [1 / 16] * 9,
+    "plus": [0, 1 / 8, 0, 1 / 8, 1 / 2, 1 / 8, 0, 1 / 8, 0],
+    "identity": [0, 0, 0, 0, 1, 0, 0, 0, 0],
+    "corners": [1 / 4, 0, 1 / 4, 0, 0, 0, 1 / 4, 0, 1 / 4],
+    "too-heavy": [1 / 4, 1 / 4, 1 / 4, 1 / 4, 1 / 4, 1 / 4, 1 / 4, 1 / 4, 1 / 4],
+    "tiny": [1 / 128, 1 / 64, 1 / 128, 1 / 64, 1 / 2, 1 / 64, 1 / 128, 1 / 64, 1 / 128],
 }
 
 
