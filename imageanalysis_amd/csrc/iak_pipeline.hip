@@ -12,28 +12,14 @@
 //     previous histogram through the table, not by another pass over the image.
 #include "iak_common.hpp"
 #include "iak_device_fns.hpp"
+#include "iak_chain.hpp"
+#include "iak_stencil_ops.hpp"
 
 #include <new>
 #include <string>
 #include <vector>
 
 namespace iak {
-
-// ---- per-pixel chain ---------------------------------------------------------------------
-enum { C_EQUALIZE = 1, C_OTSU = 2, C_CONST_LUT = 3, C_GAUSS = 4, C_SP = 5 };
-#define CHAIN_MAX 6
-
-struct ChainStage {
-    int type;
-    float mean, stddev;   // C_GAUSS
-    const uint8_t *plane; // C_GAUSS: rv plane, C_SP: code plane
-    int lut_slot;         // C_CONST_LUT: index into ChainDesc::const_lut
-};
-struct ChainDesc {
-    int n;
-    ChainStage st[CHAIN_MAX];
-    uint8_t const_lut[2][256];  // at most two constant tables per chain
-};
 
 // block-wide helpers for 256 lanes (4 waves)
 __device__ __forceinline__ long long block_sum_ll(long long v, long long *scratch4) {
@@ -174,68 +160,155 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                           long long N, long long in_stride, long long out_stride,
                                                           ChainDesc d, const uint16_t *__restrict__ tables) {
-    __shared__ uint8_t lut[CHAIN_MAX][256];
-    __shared__ uint16_t tab[CHAIN_MAX][256];
+    __shared__ ChainTables t;
     const int b = blockIdx.y;
-    const uint16_t *tb = tables + (long long)b * CHAIN_MAX * 256;
-    for (int s = 0; s < d.n; s++) {
-        if (d.st[s].type == C_GAUSS) tab[s][threadIdx.x] = tb[s * 256 + threadIdx.x];
-        else if (d.st[s].type != C_SP) lut[s][threadIdx.x] = (uint8_t)tb[s * 256 + threadIdx.x];
-    }
-    __syncthreads();
+    chain_load_tables(t, d, tables + (long long)b * CHAIN_MAX * 256);
     const uint8_t *src = in + (long long)b * in_stride;
     uint8_t *dst = out + (long long)b * out_stride;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
     long long scalar_from = 0;
     if (VEC) {
+        // two chunks per iteration: their loads are issued together, so a wave always has two
+        // independent request / look-up chains in flight
         const long long nchunks = N >> 4;
-        for (long long c = tid; c < nchunks; c += nthreads) {
-            const long long off = c << 4;
-            u32x4 v = ld16(src + off);
-            for (int s = 0; s < d.n; s++) {
-                const int type = d.st[s].type;
-                if (type == C_GAUSS) {
-                    u32x4 r = ld16(d.st[s].plane + off);
-#pragma unroll
-                    for (int w = 0; w < 4; w++) {
-                        uint32_t o = 0;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            uint32_t e = tab[s][byte_of(r[w], k)];
-                            uint32_t y = (e & 0x100u) ? 0u : ((byte_of(v[w], k) + e) & 0xffu);
-                            o |= y << (8 * k);
-                        }
-                        v[w] = o;
-                    }
-                } else if (type == C_SP) {
-                    u32x4 c4 = ld16(d.st[s].plane + off);
-#pragma unroll
-                    for (int w = 0; w < 4; w++) v[w] = sp4(v[w], c4[w]);
-                } else {
-                    v = lut16(lut[s], v);
-                }
-            }
-            st16(dst + off, v);
+        for (long long c = tid; c < nchunks; c += 2 * nthreads) {
+            const long long off0 = c << 4;
+            const bool two = c + nthreads < nchunks;
+            const long long off1 = two ? ((c + nthreads) << 4) : off0;
+            const u32x4 v0 = ld16(src + off0);
+            const u32x4 v1 = ld16(src + off1);
+            const u32x4 y0 = chain_apply16(v0, off0, d, t);
+            const u32x4 y1 = chain_apply16(v1, off1, d, t);
+            st16(dst + off0, y0);
+            if (two) st16(dst + off1, y1);
         }
         scalar_from = nchunks << 4;
     }
-    for (long long t = scalar_from + tid; t < N; t += nthreads) {
-        uint32_t p = src[t];
-        for (int s = 0; s < d.n; s++) {
-            const int type = d.st[s].type;
-            if (type == C_GAUSS) {
-                uint32_t e = tab[s][d.st[s].plane[t]];
-                p = (e & 0x100u) ? 0u : ((p + e) & 0xffu);
-            } else if (type == C_SP) {
-                uint32_t c = d.st[s].plane[t];
-                p = c == 0 ? p : (c == 2 ? 255u : 0u);
-            } else {
-                p = lut[s][p];
-            }
-        }
-        dst[t] = (uint8_t)p;
+    for (long long x = scalar_from + tid; x < N; x += nthreads) dst[x] = (uint8_t)chain_apply1(src[x], x, d, t);
+}
+
+// ---------------------------------------------------------------------------------------
+// Chain fused into the following 3x3 stencil.  A workgroup stages a tile of the CHAIN'S OUTPUT
+// in LDS -- (TH+2) rows x (TW+32) columns on the flat view of the image, every pixel pushed
+// through the chain exactly once (plus the thin halo) -- and then runs the stencil operator of
+// iak_stencil_ops.hpp on rows read from LDS instead of from memory.  The intermediate image
+// is never written: one read of the chain's input and one write of the stencil's output.
+// Pixels outside the image are staged as 0 (the reference's out-of-range taps), not as
+// chain(0).
+// ---------------------------------------------------------------------------------------
+template <class Op>
+__global__ __launch_bounds__(256) void chain_stencil8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                             int W, int H, long long in_stride, long long out_stride,
+                                                             ChainDesc d, const uint16_t *__restrict__ tables, int TW,
+                                                             int TH, int tiles_x, Op op) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int pitch = TW + 32;
+    const int tile_bytes = (TH + 2) * pitch;
+    uint8_t *tile = smem;
+    ChainTables &t = *reinterpret_cast<ChainTables *>(smem + tile_bytes);  // tile_bytes is a multiple of 16
+    const int b = blockIdx.y;
+    chain_load_tables(t, d, tables + (long long)b * CHAIN_MAX * 256);
+    const uint8_t *src = in + (long long)b * in_stride;
+    uint8_t *dst = out + (long long)b * out_stride;
+    const long long N = (long long)W * H;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+
+    // phase 1: stage chain(input) for rows y0-1 .. y0+TH, columns x0-16 .. x0+TW+15
+    const int cpr = pitch >> 4;  // 16-byte chunks per tile row
+    const int nchunks = (TH + 2) * cpr;
+    for (int c = threadIdx.x; c < nchunks; c += 2 * 256) {
+        const int c1 = c + 256;
+        const int r0 = c / cpr, k0 = c - r0 * cpr;
+        const int r1 = c1 / cpr, k1 = c1 - r1 * cpr;
+        const long long f0 = (long long)(y0 - 1 + r0) * W + (x0 - 16 + 16 * k0);
+        const long long f1 = (long long)(y0 - 1 + r1) * W + (x0 - 16 + 16 * k1);
+        const bool ok0 = f0 >= 0 && f0 < N;  // W % 16 == 0: a chunk is wholly inside or outside
+        const bool ok1 = c1 < nchunks && f1 >= 0 && f1 < N;
+        const long long g0 = ok0 ? f0 : 0, g1 = ok1 ? f1 : 0;
+        u32x4 v0 = ld16(src + g0);
+        u32x4 v1 = ld16(src + g1);
+        v0 = chain_apply16(v0, g0, d, t);
+        v1 = chain_apply16(v1, g1, d, t);
+        const u32x4 zero = {0, 0, 0, 0};
+        *reinterpret_cast<u32x4 *>(tile + r0 * pitch + 16 * k0) = ok0 ? v0 : zero;
+        if (c1 < nchunks) *reinterpret_cast<u32x4 *>(tile + r1 * pitch + 16 * k1) = ok1 ? v1 : zero;
     }
+    __syncthreads();
+
+    // phase 2: the stencil on 8-pixel chunks x groups of 8 rows, rows coming from the tile
+    const int cols = TW >> 3;
+    const int items = cols * (TH >> 3);
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int rg = it / cols, cx = it - rg * cols;
+        const int col0 = x0 + (cx << 3);
+        const int yb = y0 + (rg << 3);
+        if (col0 >= W || yb >= H) continue;
+        const uint8_t *base = tile + (rg << 3) * pitch + ((cx << 3) + 12);  // column col0-4 of tile row 8*rg
+        Raw16 raw[10];
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(base + r * pitch);
+            raw[r].d[0] = q[0]; raw[r].d[1] = q[1]; raw[r].d[2] = q[2]; raw[r].d[3] = q[3];
+        }
+        typename Op::Row up, mid, dn;
+        op.prepare(raw[0], yb - 1, col0, W, H, up);
+        op.prepare(raw[1], yb, col0, W, H, mid);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int row = yb + r;
+            op.prepare(raw[r + 2], row + 1, col0, W, H, dn);
+            uint32_t o[2];
+            op.compute(up, mid, dn, o);
+            if (Op::kBorderZero) {
+                if (row < 1) o[0] = o[1] = 0;
+                if (col0 == 0) o[0] &= 0xffffff00u;
+            }
+            if (row < H) *reinterpret_cast<uint2 *>(dst + (long long)row * W + col0) = make_uint2(o[0], o[1]);
+            up = mid;
+            mid = dn;
+        }
+    }
+}
+
+struct TileGeom {
+    int TW, TH, tiles_x, tiles_y;
+    size_t lds;
+};
+
+// Tile: as wide as the image up to 1024 columns; height 8k rows with the tile under 40 KiB
+// (four workgroups per CU) and k picked so that (TW/8)*k work items fill 256 lanes evenly.
+static TileGeom tile_geometry(int W, int H) {
+    TileGeom g;
+    g.TW = W <= 1024 ? W : 1024;
+    g.tiles_x = (W + g.TW - 1) / g.TW;
+    const int pitch = g.TW + 32;
+    int kmax = ((40960 / pitch) - 2) / 8;
+    if (kmax < 1) kmax = 1;
+    if (kmax > 8) kmax = 8;
+    int best = kmax;
+    double best_eff = -1;
+    for (int k = kmax; k >= 1 && k >= kmax - 3; k--) {
+        const int items = (g.TW / 8) * k;
+        const double eff = (double)items / (256.0 * ((items + 255) / 256));
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
+    }
+    g.TH = 8 * best;
+    g.tiles_y = (H + g.TH - 1) / g.TH;
+    g.lds = (size_t)(g.TH + 2) * pitch + sizeof(ChainTables);
+    return g;
+}
+
+template <class Op>
+static int launch_chain_stencil(const uint8_t *in, uint8_t *out, int W, int H, int B, const ChainDesc &d,
+                                const uint16_t *tables, const Op &op, hipStream_t s) {
+    const TileGeom g = tile_geometry(W, H);
+    const long long N = (long long)W * H;
+    hipLaunchKernelGGL((chain_stencil8_kernel<Op>), dim3(g.tiles_x * g.tiles_y, B), dim3(256), g.lds, s, in, out, W, H, N,
+                       N, d, tables, g.TW, g.TH, g.tiles_x, op);
+    IAK_LAUNCH_CHECK();
+    return 0;
 }
 
 // dataset histogram: sum[v] += sum_b hist[b][v]; each workgroup folds 8 images
@@ -264,7 +337,7 @@ struct OpCopy {
     std::vector<int> i;
 };
 
-enum GroupKind { G_GRAYHIST, G_HIST, G_CHAIN, G_OP };
+enum GroupKind { G_GRAYHIST, G_HIST, G_CHAIN, G_OP, G_CHAIN_OP };
 
 struct Group {
     GroupKind kind;
@@ -274,6 +347,21 @@ struct Group {
     ChainDesc chain;      // G_CHAIN
     bool chain_needs_hist = false;
 };
+
+// operators the fused chain+stencil kernel can take over (the 8-pixel 3x3 family)
+bool is_fusable_stencil(const iak_op &o) {
+    switch (o.type) {
+    case IAK_OP_LINEAR: case IAK_OP_AVERAGE: case IAK_OP_DILATE: case IAK_OP_ERODE: return o.kW == 3 && o.kH == 3;
+    case IAK_OP_MEDIAN: {
+        if (o.kW != 3 || o.kH != 3) return false;
+        for (int i = 0; i < 9; i++)
+            if (o.ikernel[i] != 1) return false;
+        return true;
+    }
+    case IAK_OP_SOBEL: case IAK_OP_COMPASS: return true;
+    default: return false;
+    }
+}
 
 bool is_pointwise(int t) {
     return t == IAK_OP_EQUALIZE || t == IAK_OP_GAUSS || t == IAK_OP_SALT_PEPPER || t == IAK_OP_THRESHOLD ||
@@ -315,6 +403,12 @@ struct iak_pipeline {
     uint32_t *x0 = nullptr, *x1 = nullptr;
     uint8_t *rv = nullptr;
     std::vector<std::pair<int, uint8_t *>> sp;  // level -> plane
+    // concurrency: the batch is cut into `lanes` sub-batches that run on their own streams, so
+    // that bandwidth-bound and issue-bound kernels of different sub-batches overlap
+    int lanes = 1;
+    std::vector<hipStream_t> aux;      // lanes - 1 extra streams
+    std::vector<hipEvent_t> fork_join; // 1 fork + (lanes - 1) join events
+    int timed_images = 0;
     // timing: `slots` sets of (groups + 1) events, run r records into set r % slots
     int slots = 0;
     std::vector<hipEvent_t> ev;
@@ -332,6 +426,8 @@ static void free_all(iak_pipeline *p) {
     for (void *q : ptrs) (void)hipFree(q);
     for (auto &e : p->sp) (void)hipFree(e.second);
     for (auto e : p->ev) (void)hipEventDestroy(e);
+    for (auto e : p->fork_join) (void)hipEventDestroy(e);
+    for (auto st : p->aux) (void)hipStreamDestroy(st);
 }
 
 static int plan(iak_pipeline *p) {
@@ -346,7 +442,7 @@ static int plan(iak_pipeline *p) {
     int i = 0;
     while (i < n) {
         const iak_op &o = p->ops[i].op;
-        if (p->mode == IAK_PIPE_FUSED && is_pointwise(o.type)) {
+        if (p->mode != IAK_PIPE_STAGEWISE && is_pointwise(o.type)) {
             Group g;
             g.kind = G_CHAIN;
             g.alg_bytes = 0;
@@ -412,6 +508,14 @@ static int plan(iak_pipeline *p) {
                 gh.alg_bytes = 1;
                 p->groups.push_back(gh);
             }
+            // the stencil right after the chain reads the chain's output from LDS instead of memory
+            if (p->mode == IAK_PIPE_FUSED && i < n && p->W % 16 == 0 && (long long)p->W * p->H < (1LL << 30) && is_fusable_stencil(p->ops[i].op)) {
+                g.kind = G_CHAIN_OP;
+                g.op_index = i;
+                g.alg_bytes += op_alg_bytes(p->ops[i].op.type);
+                g.name += std::string("+") + op_name(p->ops[i].op.type);
+                i++;
+            }
             p->groups.push_back(g);
             hist_known = false;  // conservative: a later consumer re-measures
             continue;
@@ -434,7 +538,7 @@ extern "C" {
 int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op *ops, int nops,
                         unsigned long long seed, int mode) {
     if (!out || W <= 0 || H <= 0 || maxB <= 0 || nops < 0 || (nops > 0 && !ops)) return IAK_E_ARG;
-    if (mode != IAK_PIPE_STAGEWISE && mode != IAK_PIPE_FUSED) return IAK_E_ARG;
+    if (mode != IAK_PIPE_STAGEWISE && mode != IAK_PIPE_FUSED && mode != IAK_PIPE_FUSED_POINTWISE) return IAK_E_ARG;
     iak_pipeline *p = new (std::nothrow) iak_pipeline();
     if (!p) return (int)hipErrorOutOfMemory;
     p->W = W; p->H = H; p->maxB = maxB; p->mode = mode;
@@ -551,27 +655,48 @@ int iak_pipeline_timings(iak_pipeline *p, int slot, float *ms, const char **name
     return n;
 }
 
-static int run_single_op(iak_pipeline *p, const iak_op &o, const uint8_t *src, uint8_t *dst, int B, void *stream) {
+// per-image scratch of one sub-batch
+struct Slice {
+    uint8_t *bufA, *bufB;
+    uint32_t *hist, *hist2;
+    int32_t *map, *thr;
+    uint16_t *tables;
+};
+
+static Slice slice_of(const iak_pipeline *p, int b0) {
+    Slice s;
+    s.bufA = p->bufA + (size_t)b0 * (size_t)p->N;
+    s.bufB = p->bufB + (size_t)b0 * (size_t)p->N;
+    s.hist = p->hist + (size_t)b0 * 256;
+    s.hist2 = p->hist2 + (size_t)b0 * 256;
+    s.map = p->map + (size_t)b0 * 256;
+    s.thr = p->thr + b0;
+    s.tables = p->tables + (size_t)b0 * CHAIN_MAX * 256;
+    return s;
+}
+
+static int run_single_op(iak_pipeline *p, const Slice &sl, const iak_op &o, const uint8_t *src, uint8_t *dst, int B,
+                         void *stream) {
     const int W = p->W, H = p->H;
     const long long N = p->N;
     switch (o.type) {
     case IAK_OP_EQUALIZE: {
-        int rc = iak_hist(src, p->hist2, N, B, N, stream);
+        int rc = iak_hist(src, sl.hist2, N, B, N, stream);
         if (rc) return rc;
-        rc = iak_eq_map(p->hist2, p->map, (int)N, B, stream);
+        rc = iak_eq_map(sl.hist2, sl.map, (int)N, B, stream);
         if (rc) return rc;
-        return iak_apply_map(src, dst, N, B, N, N, p->map, 256, stream);
+        return iak_apply_map(src, dst, N, B, N, N, sl.map, 256, stream);
     }
     case IAK_OP_GAUSS: {
         const bool from_image = (o.mean == -1 || o.stddev == -1);
         int rc = 0;
         if (from_image) {
-            rc = iak_hist(src, p->hist2, N, B, N, stream);
+            rc = iak_hist(src, sl.hist2, N, B, N, stream);
             if (rc) return rc;
         }
-        rc = iak_gauss_table(p->hist2, (int)N, from_image ? B : 1, o.mean, o.stddev, p->tables, stream);
+        rc = iak_gauss_table(sl.hist2, (int)N, from_image ? B : 1, o.mean, o.stddev, sl.tables, stream);
         if (rc) return rc;
-        return iak_gauss_noise(src, dst, N, B, N, N, p->rv, p->tables, from_image ? 256 : 0, stream);
+        return iak_gauss_noise(src, dst, N, B, N, N, p->rv, sl.tables, from_image ? 256 : 0, stream);
     }
     case IAK_OP_SALT_PEPPER: return iak_salt_pepper(src, dst, N, B, N, N, p->sp_plane(o.iparam), stream);
     case IAK_OP_LINEAR: return iak_linear(src, dst, W, H, B, N, N, o.fkernel, o.kW, o.kH, IAK_LINEAR_CLAMP, stream);
@@ -583,23 +708,24 @@ static int run_single_op(iak_pipeline *p, const iak_op &o, const uint8_t *src, u
     case IAK_OP_ERODE: return iak_erode(src, dst, W, H, B, N, N, o.ikernel, o.kW, o.kH, stream);
     case IAK_OP_THRESHOLD: return iak_threshold(src, dst, N, B, N, N, o.iparam, stream);
     case IAK_OP_OTSU: {
-        int rc = iak_hist(src, p->hist2, N, B, N, stream);
+        int rc = iak_hist(src, sl.hist2, N, B, N, stream);
         if (rc) return rc;
-        rc = iak_otsu_threshold(p->hist2, p->thr, (int)N, B, stream);
+        rc = iak_otsu_threshold(sl.hist2, sl.thr, (int)N, B, stream);
         if (rc) return rc;
-        return iak_threshold_per_image(src, dst, N, B, N, N, p->thr, stream);
+        return iak_threshold_per_image(src, dst, N, B, N, N, sl.thr, stream);
     }
     case IAK_OP_QUANTIZE: return iak_quantize(src, dst, N, B, N, N, o.ikernel, o.iparam, stream);
     }
     return IAK_E_ARG;
 }
 
-int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, unsigned long long *hist_sum,
-                     uint32_t *gray_hist, void *stream) {
-    if (!p || !rgb || !out || B <= 0 || B > p->maxB) return IAK_E_ARG;
-    hipStream_t s = as_stream(stream);
+static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, int B, unsigned long long *hist_sum,
+                     uint32_t *gray_hist, hipStream_t s, const hipEvent_t *ev) {
     const long long N = p->N;
     const int ng = (int)p->groups.size();
+    const Slice sl = slice_of(p, b0);
+    rgb += (size_t)b0 * 3 * (size_t)N;
+    out += (size_t)b0 * (size_t)N;
     // image-producing groups alternate between the two buffers; the last one writes `out`
     int producers = 0;
     for (auto &g : p->groups)
@@ -607,15 +733,14 @@ int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, u
     int produced = 0;
     const uint8_t *cur = nullptr;
     const uint32_t *cur_hist = nullptr;
-    uint32_t *ghist = gray_hist ? gray_hist : p->hist;
-    const hipEvent_t *ev = p->slots ? p->ev.data() + (size_t)(p->runs_timed % p->slots) * (ng + 1) : nullptr;
+    uint32_t *ghist = gray_hist ? gray_hist + (size_t)b0 * 256 : sl.hist;
     if (ev) IAK_HIP(hipEventRecord(ev[0], s));
     for (int gi = 0; gi < ng; gi++) {
         const Group &g = p->groups[gi];
         uint8_t *dst = nullptr;
         if (g.kind != G_HIST) {
             produced++;
-            dst = (produced == producers) ? out : ((produced & 1) ? p->bufA : p->bufB);
+            dst = (produced == producers) ? out : ((produced & 1) ? sl.bufA : sl.bufB);
         }
         int rc = 0;
         switch (g.kind) {
@@ -629,8 +754,8 @@ int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, u
             cur_hist = ghist;
             break;
         case G_HIST:
-            rc = iak_hist(cur, p->hist2, N, B, N, s);
-            cur_hist = p->hist2;
+            rc = iak_hist(cur, sl.hist2, N, B, N, s);
+            cur_hist = sl.hist2;
             break;
         case G_CHAIN: {
             bool wants = false;
@@ -638,28 +763,108 @@ int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, u
                 wants = wants || g.chain.st[k].type == C_EQUALIZE || g.chain.st[k].type == C_OTSU ||
                         (g.chain.st[k].type == C_GAUSS && (g.chain.st[k].mean == -1 || g.chain.st[k].stddev == -1));
             if (wants && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
-            hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, g.chain, p->tables);
+            hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, g.chain, sl.tables);
             IAK_LAUNCH_CHECK();
             bool vec = aligned16(cur) && aligned16(dst) && N % 16 == 0;
             for (int k = 0; k < g.chain.n; k++)
                 if (g.chain.st[k].plane) vec = vec && aligned16(g.chain.st[k].plane);
-            dim3 grid(blocks_x(vec ? N / 16 : N, 256, B), B);
+            dim3 grid(blocks_x(vec ? N / 32 : N, 256, B, 32768), B);
             if (vec)
-                hipLaunchKernelGGL((chain_apply_kernel<true>), grid, dim3(256), 0, s, cur, dst, N, N, N, g.chain, p->tables);
+                hipLaunchKernelGGL((chain_apply_kernel<true>), grid, dim3(256), 0, s, cur, dst, N, N, N, g.chain, sl.tables);
             else
-                hipLaunchKernelGGL((chain_apply_kernel<false>), grid, dim3(256), 0, s, cur, dst, N, N, N, g.chain, p->tables);
+                hipLaunchKernelGGL((chain_apply_kernel<false>), grid, dim3(256), 0, s, cur, dst, N, N, N, g.chain, sl.tables);
             IAK_LAUNCH_CHECK();
             cur_hist = nullptr;
             break;
         }
+        case G_CHAIN_OP: {
+            bool wants = false;
+            for (int k = 0; k < g.chain.n; k++)
+                wants = wants || g.chain.st[k].type == C_EQUALIZE || g.chain.st[k].type == C_OTSU ||
+                        (g.chain.st[k].type == C_GAUSS && (g.chain.st[k].mean == -1 || g.chain.st[k].stddev == -1));
+            if (wants && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
+            if (!aligned16(cur) || (reinterpret_cast<uintptr_t>(dst) & 7u)) return IAK_E_UNSUPPORTED;
+            for (int k = 0; k < g.chain.n; k++)
+                if (g.chain.st[k].plane && !aligned16(g.chain.st[k].plane)) return IAK_E_UNSUPPORTED;
+            hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, g.chain, sl.tables);
+            IAK_LAUNCH_CHECK();
+            const iak_op &o = p->ops[g.op_index].op;
+            auto go = [&](const auto &op) {
+                return launch_chain_stencil(cur, dst, p->W, p->H, B, g.chain, sl.tables, op, s);
+            };
+            switch (o.type) {
+            case IAK_OP_LINEAR: rc = with_linear3_op<false>(o.fkernel, go); break;
+            case IAK_OP_AVERAGE: rc = with_linear3_op<true>(o.fkernel, go); break;
+            case IAK_OP_MEDIAN: rc = go(Median8()); break;
+            case IAK_OP_SOBEL: rc = go(Sobel8()); break;
+            case IAK_OP_COMPASS: rc = go(Compass8()); break;
+            case IAK_OP_ERODE: { Erode8 op; op.mask = se_mask3(o.ikernel); rc = go(op); break; }
+            case IAK_OP_DILATE: { Dilate8 op; op.mask = se_mask3(o.ikernel); rc = go(op); break; }
+            default: rc = IAK_E_UNSUPPORTED; break;
+            }
+            cur_hist = nullptr;
+            break;
+        }
         case G_OP:
-            rc = run_single_op(p, p->ops[g.op_index].op, cur, dst, B, s);
+            rc = run_single_op(p, sl, p->ops[g.op_index].op, cur, dst, B, s);
             cur_hist = nullptr;
             break;
         }
         if (rc) return rc;
         if (dst) cur = dst;
         if (ev) IAK_HIP(hipEventRecord(ev[gi + 1], s));
+    }
+    return 0;
+}
+
+int iak_pipeline_set_lanes(iak_pipeline *p, int lanes) {
+    if (!p || lanes < 1 || lanes > 8) return IAK_E_ARG;
+    while ((int)p->aux.size() < lanes - 1) {
+        hipStream_t st;
+        IAK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        p->aux.push_back(st);
+    }
+    while ((int)p->fork_join.size() < lanes) {
+        hipEvent_t e;
+        IAK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->fork_join.push_back(e);
+    }
+    p->lanes = lanes;
+    return 0;
+}
+
+int iak_pipeline_timed_images(iak_pipeline *p) { return p ? p->timed_images : IAK_E_ARG; }
+
+int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, unsigned long long *hist_sum,
+                     uint32_t *gray_hist, void *stream) {
+    if (!p || !rgb || !out || B <= 0 || B > p->maxB) return IAK_E_ARG;
+    hipStream_t s = as_stream(stream);
+    const int ng = (int)p->groups.size();
+    const hipEvent_t *ev = p->slots ? p->ev.data() + (size_t)(p->runs_timed % p->slots) * (ng + 1) : nullptr;
+    const int lanes = (p->lanes > B) ? B : p->lanes;
+    if (lanes <= 1) {
+        int rc = run_range(p, rgb, out, 0, B, hist_sum, gray_hist, s, ev);
+        if (rc) return rc;
+        p->timed_images = B;
+    } else {
+        // fork: every extra stream starts after the work already queued on the caller's stream
+        IAK_HIP(hipEventRecord(p->fork_join[0], s));
+        const int per = (B + lanes - 1) / lanes;
+        for (int l = 1; l < lanes; l++) {
+            const int b0 = l * per;
+            const int nb = (b0 + per <= B) ? per : (B - b0);
+            if (nb <= 0) continue;
+            hipStream_t sx = p->aux[l - 1];
+            IAK_HIP(hipStreamWaitEvent(sx, p->fork_join[0], 0));
+            int rc = run_range(p, rgb, out, b0, nb, hist_sum, gray_hist, sx, nullptr);
+            if (rc) return rc;
+            IAK_HIP(hipEventRecord(p->fork_join[l], sx));
+        }
+        int rc = run_range(p, rgb, out, 0, per, hist_sum, gray_hist, s, ev);  // sub-batch 0 carries the timing events
+        if (rc) return rc;
+        p->timed_images = per;
+        for (int l = 1; l < lanes; l++)  // join
+            if (l * per < B) IAK_HIP(hipStreamWaitEvent(s, p->fork_join[l], 0));
     }
     if (ev) p->runs_timed++;
     return 0;

@@ -209,10 +209,12 @@ __device__ __forceinline__ uint32_t gray4(uint32_t r, uint32_t g, uint32_t b) {
     return o;
 }
 
+// 1024 lanes share one 32 KiB histogram table, so two workgroups (32 waves) fit a CU.
+#define GRAY_THREADS 1024
 template <int METHOD, bool HIST, bool VEC>
-__global__ __launch_bounds__(256) void gray_kernel(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ gray,
-                                                   uint32_t *__restrict__ hist, long long N, long long rgb_stride,
-                                                   long long gray_stride) {
+__global__ __launch_bounds__(GRAY_THREADS) void gray_kernel(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ gray,
+                                                            uint32_t *__restrict__ hist, long long N,
+                                                            long long rgb_stride, long long gray_stride) {
     __shared__ uint32_t sh[HIST ? 256 * HIST_COLS : 1];
     const int b = blockIdx.y;
     const uint8_t *R = rgb + (long long)b * rgb_stride;
@@ -225,16 +227,30 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t *__restrict__ r
     const long long nthreads = (long long)gridDim.x * blockDim.x;
     long long scalar_from = 0;
     if (VEC) {
+        // two chunks per iteration so that six loads are in flight per lane
         const long long nchunks = N >> 4;
-        for (long long c = tid; c < nchunks; c += nthreads) {
-            u32x4 r = ld16(R + (c << 4)), g = ld16(G + (c << 4)), bl = ld16(Bp + (c << 4));
-            u32x4 o;
+        for (long long c = tid; c < nchunks; c += 2 * nthreads) {
+            const long long o0 = c << 4;
+            const bool two = c + nthreads < nchunks;
+            const long long o1 = two ? ((c + nthreads) << 4) : o0;
+            const u32x4 r0 = ld16(R + o0), g0 = ld16(G + o0), b0 = ld16(Bp + o0);
+            const u32x4 r1 = ld16(R + o1), g1 = ld16(G + o1), b1 = ld16(Bp + o1);
+            u32x4 y0, y1;
 #pragma unroll
-            for (int w = 0; w < 4; w++) o[w] = gray4<METHOD>(r[w], g[w], bl[w]);
-            st16(dst + (c << 4), o);
+            for (int w = 0; w < 4; w++) y0[w] = gray4<METHOD>(r0[w], g0[w], b0[w]);
+            st16(dst + o0, y0);
             if (HIST) {
 #pragma unroll
-                for (int w = 0; w < 4; w++) hist_add4(sh, o[w], col);
+                for (int w = 0; w < 4; w++) hist_add4(sh, y0[w], col);
+            }
+            if (two) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) y1[w] = gray4<METHOD>(r1[w], g1[w], b1[w]);
+                st16(dst + o1, y1);
+                if (HIST) {
+#pragma unroll
+                    for (int w = 0; w < 4; w++) hist_add4(sh, y1[w], col);
+                }
             }
         }
         scalar_from = nchunks << 4;
@@ -318,16 +334,22 @@ int iak_gray_hist(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int 
     if (rgb_stride < 3 * N || gray_stride < N) return IAK_E_ARG;
     const bool vec = aligned16(rgb) && aligned16(gray) && rgb_stride % 16 == 0 && gray_stride % 16 == 0 && N % 16 == 0;
     hipStream_t s = as_stream(stream);
-    dim3 block(256);
+    dim3 block(GRAY_THREADS);
     if (hist) {
         IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
-        dim3 grid(hist_blocks_x(N, B), B);
+        // every workgroup pays a 32 KiB clear and a 256-atomic merge: at least 128K pixels each,
+        // and about 2-4 workgroups per CU over the whole launch
+        long long bx = (1024 + B - 1) / B;
+        const long long by_work = (N + 131071) / 131072;
+        if (bx > by_work) bx = by_work;
+        if (bx < 1) bx = 1;
+        dim3 grid((unsigned)bx, B);
 #define GH(M, V) hipLaunchKernelGGL((gray_kernel<M, true, V>), grid, block, 0, s, rgb, gray, hist, N, rgb_stride, gray_stride)
         if (method == 0) { if (vec) GH(0, true); else GH(0, false); }
         else { if (vec) GH(1, true); else GH(1, false); }
 #undef GH
     } else {
-        dim3 grid(blocks_x(vec ? N / 16 : N, 256, B), B);
+        dim3 grid(blocks_x(vec ? N / 32 : N, GRAY_THREADS, B, 2048), B);
 #define GN(M, V) hipLaunchKernelGGL((gray_kernel<M, false, V>), grid, block, 0, s, rgb, gray, (uint32_t *)nullptr, N, rgb_stride, gray_stride)
         if (method == 0) { if (vec) GN(0, true); else GN(0, false); }
         else { if (vec) GN(1, true); else GN(1, false); }

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libiak.so")
 
 IAK_E_ARG, IAK_E_UNSUPPORTED, IAK_E_TOO_LARGE = -1, -2, -3
 IAK_LINEAR_CLAMP, IAK_LINEAR_AVERAGE = 0, 1
-IAK_PIPE_STAGEWISE, IAK_PIPE_FUSED = 0, 1
+IAK_PIPE_STAGEWISE, IAK_PIPE_FUSED, IAK_PIPE_FUSED_POINTWISE = 0, 1, 2
 (IAK_OP_EQUALIZE, IAK_OP_GAUSS, IAK_OP_SALT_PEPPER, IAK_OP_LINEAR, IAK_OP_AVERAGE, IAK_OP_MEDIAN, IAK_OP_SOBEL,
  IAK_OP_COMPASS, IAK_OP_DILATE, IAK_OP_ERODE, IAK_OP_THRESHOLD, IAK_OP_OTSU, IAK_OP_QUANTIZE) = range(1, 14)
 
@@ -58,6 +58,8 @@ SIGNATURES = {
     "iak_pipeline_create": [C.POINTER(_vp), _i, _i, _i, _vp, _i, C.c_ulonglong, _i],
     "iak_pipeline_destroy": [_vp],
     "iak_pipeline_run": [_vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "iak_pipeline_set_lanes": [_vp, _i],
+    "iak_pipeline_timed_images": [_vp],
     "iak_pipeline_set_timing": [_vp, _i],
     "iak_pipeline_timings": [_vp, _i, _vp, _vp, _vp, _i],
 }

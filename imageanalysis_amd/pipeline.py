@@ -51,7 +51,9 @@ def ops_from_config(operations):
 
 class Pipeline:
     """Owns an iak_pipeline.  ops: list of dicts with keys type, kW, kH, fkernel, ikernel,
-    iparam, mean, stddev (same meaning as iak_op)."""
+    iparam, mean, stddev (same meaning as iak_op).  fused: True (per-pixel runs fused, and fed
+    straight into the 3x3 stencil behind them), "pointwise" (per-pixel runs fused only) or
+    False (one pass per operation)."""
 
     def __init__(self, W, H, maxB, ops, seed=1234, fused=True, device=None):
         self.W, self.H, self.maxB = int(W), int(H), int(maxB)
@@ -75,8 +77,10 @@ class Pipeline:
             arr[i].stddev = o.get("stddev", -1.0)
         self._h = C.c_void_p()
         L = _l.load()
-        _l.check(L.iak_pipeline_create(C.byref(self._h), self.W, self.H, self.maxB, arr, len(ops), seed,
-                                       _l.IAK_PIPE_FUSED if fused else _l.IAK_PIPE_STAGEWISE), "iak_pipeline_create")
+        mode = (_l.IAK_PIPE_FUSED_POINTWISE if fused == "pointwise" else
+                _l.IAK_PIPE_FUSED if fused else _l.IAK_PIPE_STAGEWISE)
+        _l.check(L.iak_pipeline_create(C.byref(self._h), self.W, self.H, self.maxB, arr, len(ops), seed, mode),
+                 "iak_pipeline_create")
         del keep  # the executor copied every host array
 
     def close(self):
@@ -108,6 +112,13 @@ class Pipeline:
             gray_hist.data_ptr() if gray_hist is not None else None, torch.cuda.current_stream().cuda_stream),
             "iak_pipeline_run")
         return out
+
+    def set_lanes(self, lanes):
+        """Run every batch as `lanes` concurrent sub-batches (see iak_pipeline_set_lanes)."""
+        _l.check(_l.load().iak_pipeline_set_lanes(self._h, int(lanes)), "iak_pipeline_set_lanes")
+
+    def timed_images(self):
+        return _l.load().iak_pipeline_timed_images(self._h)
 
     def set_timing(self, slots):
         """Record per-group HIP events for the next runs, into `slots` rotating sets."""

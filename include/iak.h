@@ -190,7 +190,8 @@ typedef struct {
 } iak_op;
 
 #define IAK_PIPE_STAGEWISE 0 /* one launch (or more) per operation, every intermediate image written */
-#define IAK_PIPE_FUSED 1     /* runs of per-pixel operations and runs of 3x3 stencils share one pass */
+#define IAK_PIPE_FUSED 1     /* runs of per-pixel operations share one pass, and that pass also feeds the 3x3 stencil behind it */
+#define IAK_PIPE_FUSED_POINTWISE 2 /* as FUSED, but every stencil stays a pass of its own */
 #define IAK_PIPE_MAX_STAGES 64
 
 typedef struct iak_pipeline iak_pipeline;
@@ -206,6 +207,13 @@ int iak_pipeline_destroy(iak_pipeline *p);
  * gray_hist: DEVICE [B][256] uint32 per-image grayscale histograms, or NULL. */
 int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B,
                      unsigned long long *hist_sum, uint32_t *gray_hist, void *stream);
+/* Cuts every batch into `lanes` (1..8) consecutive sub-batches that run concurrently on
+ * library-owned streams forked from / joined to the caller's stream, so that bandwidth-bound
+ * and issue-bound kernels of different sub-batches overlap.  Results are unchanged.  This call
+ * may create streams and events; runs do not.  Default 1. */
+int iak_pipeline_set_lanes(iak_pipeline *p, int lanes);
+/* Number of images the timed sub-batch of the most recent run held (all of them with 1 lane). */
+int iak_pipeline_timed_images(iak_pipeline *p);
 /* Per-launch-group timing.  set_timing(p, slots) (re)creates `slots` sets of HIP events
  * (0 disables; this call allocates events, runs do not); run number r then records one event
  * between launch groups into set r % slots, counting runs from the set_timing call.

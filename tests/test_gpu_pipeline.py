@@ -56,6 +56,16 @@ CHAINS = {
     "fixed-gauss": [{"type": O.OP_GAUSS, "mean": 120.0, "stddev": 30.0}, {"type": O.OP_THRESHOLD, "iparam": 100},
                     {"type": O.OP_THRESHOLD, "iparam": 10}, {"type": O.OP_THRESHOLD, "iparam": 200},
                     {"type": O.OP_SALT_PEPPER, "iparam": 3}, {"type": O.OP_SALT_PEPPER, "iparam": 50}],
+    # a per-pixel run feeding each kind of 3x3 stencil (the executor stages the run's output in LDS)
+    "sp+median": [{"type": O.OP_SALT_PEPPER, "iparam": 20}, {"type": O.OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": ONES9}],
+    "eq+sobel": [{"type": O.OP_EQUALIZE}, {"type": O.OP_SOBEL}],
+    "gauss+compass": [{"type": O.OP_GAUSS, "mean": 10.0, "stddev": 25.0}, {"type": O.OP_COMPASS}],
+    "otsu+dilate+erode": [{"type": O.OP_OTSU}, {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": CROSS},
+                          {"type": O.OP_THRESHOLD, "iparam": 100}, {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": ONES9}],
+    "quant+average": [{"type": O.OP_QUANTIZE, "ikernel": [0, 128, 40, 128, 256, 220], "iparam": 2},
+                      {"type": O.OP_AVERAGE, "kW": 3, "kH": 3, "fkernel": [1.0] * 9},
+                      {"type": O.OP_THRESHOLD, "iparam": 90},
+                      {"type": O.OP_LINEAR, "kW": 3, "kH": 3, "fkernel": [0.3, -0.2, 0.1, 0.7, 1.1, -0.4, 0.25, 0.05, 0.6]}],
     "big-stencils": [{"type": O.OP_LINEAR, "kW": 11, "kH": 11, "fkernel": [1.0 / 121] * 121},
                      {"type": O.OP_MEDIAN, "kW": 7, "kH": 7, "ikernel": [1] * 49}],
 }
@@ -69,8 +79,8 @@ def Pipeline():
 
 
 @pytest.mark.parametrize("name", list(CHAINS))
-@pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("W,H,kind", [(64, 48, "C"), (37, 23, "U"), (768, 40, "C")])
+@pytest.mark.parametrize("fused", [False, "pointwise", True])
+@pytest.mark.parametrize("W,H,kind", [(64, 48, "C"), (37, 23, "U"), (768, 40, "C"), (48, 203, "U"), (1056, 21, "U")])
 def test_pipeline_matches_oracle(Pipeline, name, fused, W, H, kind):
     ops = CHAINS[name]
     B = 3
@@ -106,6 +116,27 @@ def test_pipeline_smaller_batch_than_planned(Pipeline):
     assert np.array_equal(full, want) and np.array_equal(part, want[:2])
 
 
+@pytest.mark.parametrize("lanes", [2, 3, 8])
+@pytest.mark.parametrize("name", ["P-A", "input.json"])
+def test_pipeline_lanes_do_not_change_results(Pipeline, lanes, name):
+    W, H, B = 64, 48, 5
+    ops = CHAINS[name]
+    rgb = synth.rgb_batch("C", W, H, B)
+    x0, x1 = O.xorwow_planes(W * H)
+    want, want_hist = O.pipeline(rgb, ops, x0, x1)
+    p = Pipeline(W, H, B, ops, fused=True)
+    p.set_lanes(lanes)
+    hs = torch.zeros(256, dtype=torch.int64, device="cuda")
+    gh = torch.empty((B, 256), dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        got = p.run(torch.from_numpy(rgb).cuda(), hist_sum=hs, gray_hist=gh)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(hs.cpu().numpy(), 3 * want_hist)
+    for b in range(B):
+        assert np.array_equal(gh[b].cpu().numpy(), O.hist(O.gray(rgb[b], 0)))
+
+
 def test_pipeline_timings(Pipeline):
     W, H = 64, 48
     rgb = torch.from_numpy(synth.rgb_batch("C", W, H, 2)).cuda()
@@ -115,6 +146,7 @@ def test_pipeline_timings(Pipeline):
     p.run(rgb)
     t = p.timings(1)
     names = [n for n, _, _ in t]
-    assert names[0] == "gray+hist" and "equalize+gauss+salt_pepper" in names
+    assert names[0] == "gray+hist" and "equalize+gauss+salt_pepper+linear" in names
+    assert [n for n, _ in Pipeline(W, H, 2, P_A, fused="pointwise").groups()][1:3] == ["equalize+gauss+salt_pepper", "linear"]
     assert sum(b for _, _, b in t) == 19  # stage-wise compulsory bytes per pixel of this pipeline
     assert all(ms >= 0 for _, ms, _ in t)
