@@ -176,12 +176,12 @@ __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restr
             const long long off0 = c << 4;
             const bool two = c + nthreads < nchunks;
             const long long off1 = two ? ((c + nthreads) << 4) : off0;
-            const u32x4 v0 = ld16(src + off0);
-            const u32x4 v1 = ld16(src + off1);
+            const u32x4 v0 = ld16<IAK_NT_CHAIN_LD>(src + off0);
+            const u32x4 v1 = ld16<IAK_NT_CHAIN_LD>(src + off1);
             const u32x4 y0 = chain_apply16(v0, off0, d, t);
             const u32x4 y1 = chain_apply16(v1, off1, d, t);
-            st16(dst + off0, y0);
-            if (two) st16(dst + off1, y1);
+            st16<IAK_NT_CHAIN_ST>(dst + off0, y0);
+            if (two) st16<IAK_NT_CHAIN_ST>(dst + off1, y1);
         }
         scalar_from = nchunks << 4;
     }
@@ -197,8 +197,9 @@ __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restr
 // Pixels outside the image are staged as 0 (the reference's out-of-range taps), not as
 // chain(0).
 // ---------------------------------------------------------------------------------------
+#define CS_THREADS 512
 template <class Op>
-__global__ __launch_bounds__(256) void chain_stencil8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(CS_THREADS) void chain_stencil8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                              int W, int H, long long in_stride, long long out_stride,
                                                              ChainDesc d, const uint16_t *__restrict__ tables, int TW,
                                                              int TH, int tiles_x, Op op) {
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(256) void chain_stencil8_kernel(const uint8_t *__re
     // phase 1: stage chain(input) for rows y0-1 .. y0+TH, columns x0-16 .. x0+TW+15
     const int cpr = pitch >> 4;  // 16-byte chunks per tile row
     const int nchunks = (TH + 2) * cpr;
-    for (int c = threadIdx.x; c < nchunks; c += 2 * 256) {
-        const int c1 = c + 256;
+    for (int c = threadIdx.x; c < nchunks; c += 2 * CS_THREADS) {
+        const int c1 = c + CS_THREADS;
         const int r0 = c / cpr, k0 = c - r0 * cpr;
         const int r1 = c1 / cpr, k1 = c1 - r1 * cpr;
         const long long f0 = (long long)(y0 - 1 + r0) * W + (x0 - 16 + 16 * k0);
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(256) void chain_stencil8_kernel(const uint8_t *__re
         const bool ok0 = f0 >= 0 && f0 < N;  // W % 16 == 0: a chunk is wholly inside or outside
         const bool ok1 = c1 < nchunks && f1 >= 0 && f1 < N;
         const long long g0 = ok0 ? f0 : 0, g1 = ok1 ? f1 : 0;
-        u32x4 v0 = ld16(src + g0);
-        u32x4 v1 = ld16(src + g1);
+        u32x4 v0 = ld16<IAK_NT_CHAIN_LD>(src + g0);
+        u32x4 v1 = ld16<IAK_NT_CHAIN_LD>(src + g1);
         v0 = chain_apply16(v0, g0, d, t);
         v1 = chain_apply16(v1, g1, d, t);
         const u32x4 zero = {0, 0, 0, 0};
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void chain_stencil8_kernel(const uint8_t *__re
     // phase 2: the stencil on 8-pixel chunks x groups of 8 rows, rows coming from the tile
     const int cols = TW >> 3;
     const int items = cols * (TH >> 3);
-    for (int it = threadIdx.x; it < items; it += 256) {
+    for (int it = threadIdx.x; it < items; it += CS_THREADS) {
         const int rg = it / cols, cx = it - rg * cols;
         const int col0 = x0 + (cx << 3);
         const int yb = y0 + (rg << 3);
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void chain_stencil8_kernel(const uint8_t *__re
                 if (row < 1) o[0] = o[1] = 0;
                 if (col0 == 0) o[0] &= 0xffffff00u;
             }
-            if (row < H) *reinterpret_cast<uint2 *>(dst + (long long)row * W + col0) = make_uint2(o[0], o[1]);
+            if (row < H) st8<IAK_NT_STENCIL_ST>(dst + (long long)row * W + col0, o[0], o[1]);
             up = mid;
             mid = dn;
         }
@@ -278,7 +279,7 @@ struct TileGeom {
 };
 
 // Tile: as wide as the image up to 1024 columns; height 8k rows with the tile under 40 KiB
-// (four workgroups per CU) and k picked so that (TW/8)*k work items fill 256 lanes evenly.
+// (four workgroups per CU) and k picked so that (TW/8)*k work items fill the workgroup's lanes evenly.
 static TileGeom tile_geometry(int W, int H) {
     TileGeom g;
     g.TW = W <= 1024 ? W : 1024;
@@ -291,7 +292,7 @@ static TileGeom tile_geometry(int W, int H) {
     double best_eff = -1;
     for (int k = kmax; k >= 1 && k >= kmax - 3; k--) {
         const int items = (g.TW / 8) * k;
-        const double eff = (double)items / (256.0 * ((items + 255) / 256));
+        const double eff = (double)items / ((double)CS_THREADS * ((items + CS_THREADS - 1) / CS_THREADS));
         if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
     }
     g.TH = 8 * best;
@@ -305,7 +306,7 @@ static int launch_chain_stencil(const uint8_t *in, uint8_t *out, int W, int H, i
                                 const uint16_t *tables, const Op &op, hipStream_t s) {
     const TileGeom g = tile_geometry(W, H);
     const long long N = (long long)W * H;
-    hipLaunchKernelGGL((chain_stencil8_kernel<Op>), dim3(g.tiles_x * g.tiles_y, B), dim3(256), g.lds, s, in, out, W, H, N,
+    hipLaunchKernelGGL((chain_stencil8_kernel<Op>), dim3(g.tiles_x * g.tiles_y, B), dim3(CS_THREADS), g.lds, s, in, out, W, H, N,
                        N, d, tables, g.TW, g.TH, g.tiles_x, op);
     IAK_LAUNCH_CHECK();
     return 0;
@@ -409,7 +410,11 @@ struct iak_pipeline {
     std::vector<hipStream_t> aux;      // lanes - 1 extra streams
     std::vector<hipEvent_t> fork_join; // 1 fork + (lanes - 1) join events
     int timed_images = 0;
-    // timing: `slots` sets of (groups + 1) events, run r records into set r % slots
+    // timing: `slots` sets of (2 * groups + 1) events, run r records into set r % slots: event 0
+    // at the start, then per group a split event (between its helper launch and its main
+    // kernel, when it has a helper) and an end event.  split[g]: 0 no helper, 1 helper first,
+    // 2 main kernel first.
+    std::vector<int> split;
     int slots = 0;
     std::vector<hipEvent_t> ev;
     long long runs_timed = 0;
@@ -628,7 +633,8 @@ int iak_pipeline_set_timing(iak_pipeline *p, int slots) {
     p->ev.clear();
     p->slots = 0;
     p->runs_timed = 0;
-    const size_t per = p->groups.size() + 1;
+    const size_t per = 2 * p->groups.size() + 1;
+    p->split.assign(p->groups.size(), 0);
     for (size_t i = 0; i < per * (size_t)slots; i++) {
         hipEvent_t e;
         IAK_HIP(hipEventCreate(&e));
@@ -638,15 +644,23 @@ int iak_pipeline_set_timing(iak_pipeline *p, int slots) {
     return 0;
 }
 
-int iak_pipeline_timings(iak_pipeline *p, int slot, float *ms, const char **names, long long *alg_bytes_per_px,
-                         int cap) {
+int iak_pipeline_timings(iak_pipeline *p, int slot, float *ms, float *main_ms, const char **names,
+                         long long *alg_bytes_per_px, int cap) {
     if (!p) return IAK_E_ARG;
     const int n = (int)p->groups.size();
-    if (ms) {
+    if (ms || main_ms) {
         if (slot < 0 || slot >= p->slots || slot >= p->runs_timed) return IAK_E_ARG;
-        const hipEvent_t *ev = p->ev.data() + (size_t)slot * (n + 1);
-        IAK_HIP(hipEventSynchronize(ev[n]));
-        for (int i = 0; i < n && i < cap; i++) IAK_HIP(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+        const hipEvent_t *ev = p->ev.data() + (size_t)slot * (2 * n + 1);
+        IAK_HIP(hipEventSynchronize(ev[2 * n]));
+        for (int i = 0; i < n && i < cap; i++) {
+            const hipEvent_t e0 = ev[2 * i], es = ev[2 * i + 1], e1 = ev[2 * i + 2];
+            if (ms) IAK_HIP(hipEventElapsedTime(&ms[i], e0, e1));
+            if (main_ms) {
+                if (p->split[i] == 1) IAK_HIP(hipEventElapsedTime(&main_ms[i], es, e1));
+                else if (p->split[i] == 2) IAK_HIP(hipEventElapsedTime(&main_ms[i], e0, es));
+                else IAK_HIP(hipEventElapsedTime(&main_ms[i], e0, e1));
+            }
+        }
     }
     for (int i = 0; i < n && i < cap; i++) {
         if (names) names[i] = p->groups[i].name.c_str();
@@ -746,7 +760,9 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
         switch (g.kind) {
         case G_GRAYHIST:
             rc = iak_gray_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, 0, s);
+            if (ev) p->split[gi] = hist_sum ? 2 : 0;
             if (rc == 0 && hist_sum) {
+                if (ev) IAK_HIP(hipEventRecord(ev[2 * gi + 1], s));
                 hipLaunchKernelGGL(hist_accumulate_kernel, dim3((B + ACC_IMAGES - 1) / ACC_IMAGES), dim3(256), 0, s, ghist, B,
                                    hist_sum);
                 IAK_LAUNCH_CHECK();
@@ -765,6 +781,10 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             if (wants && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
             hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, g.chain, sl.tables);
             IAK_LAUNCH_CHECK();
+            if (ev) {
+                p->split[gi] = 1;
+                IAK_HIP(hipEventRecord(ev[2 * gi + 1], s));
+            }
             bool vec = aligned16(cur) && aligned16(dst) && N % 16 == 0;
             for (int k = 0; k < g.chain.n; k++)
                 if (g.chain.st[k].plane) vec = vec && aligned16(g.chain.st[k].plane);
@@ -788,6 +808,10 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
                 if (g.chain.st[k].plane && !aligned16(g.chain.st[k].plane)) return IAK_E_UNSUPPORTED;
             hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, g.chain, sl.tables);
             IAK_LAUNCH_CHECK();
+            if (ev) {
+                p->split[gi] = 1;
+                IAK_HIP(hipEventRecord(ev[2 * gi + 1], s));
+            }
             const iak_op &o = p->ops[g.op_index].op;
             auto go = [&](const auto &op) {
                 return launch_chain_stencil(cur, dst, p->W, p->H, B, g.chain, sl.tables, op, s);
@@ -812,7 +836,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
         }
         if (rc) return rc;
         if (dst) cur = dst;
-        if (ev) IAK_HIP(hipEventRecord(ev[gi + 1], s));
+        if (ev) IAK_HIP(hipEventRecord(ev[2 * gi + 2], s));
     }
     return 0;
 }
@@ -840,7 +864,7 @@ int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, u
     if (!p || !rgb || !out || B <= 0 || B > p->maxB) return IAK_E_ARG;
     hipStream_t s = as_stream(stream);
     const int ng = (int)p->groups.size();
-    const hipEvent_t *ev = p->slots ? p->ev.data() + (size_t)(p->runs_timed % p->slots) * (ng + 1) : nullptr;
+    const hipEvent_t *ev = p->slots ? p->ev.data() + (size_t)(p->runs_timed % p->slots) * (2 * ng + 1) : nullptr;
     const int lanes = (p->lanes > B) ? B : p->lanes;
     if (lanes <= 1) {
         int rc = run_range(p, rgb, out, 0, B, hist_sum, gray_hist, s, ev);

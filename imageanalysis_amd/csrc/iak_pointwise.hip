@@ -27,8 +27,8 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const uint8_t *__restric
     if (VEC) {
         const long long nchunks = N >> 4;
         for (long long c = tid; c < nchunks; c += nthreads) {
-            u32x4 v = ld16(src + (c << 4));
-            st16(dst + (c << 4), f.apply16(v, c << 4));
+            u32x4 v = ld16<IAK_NT_CHAIN_LD>(src + (c << 4));
+            st16<IAK_NT_CHAIN_ST>(dst + (c << 4), f.apply16(v, c << 4));
         }
         for (long long t = (nchunks << 4) + tid; t < N; t += nthreads) dst[t] = (uint8_t)f.apply1(src[t], t);
     } else {
@@ -233,12 +233,12 @@ __global__ __launch_bounds__(GRAY_THREADS) void gray_kernel(const uint8_t *__res
             const long long o0 = c << 4;
             const bool two = c + nthreads < nchunks;
             const long long o1 = two ? ((c + nthreads) << 4) : o0;
-            const u32x4 r0 = ld16(R + o0), g0 = ld16(G + o0), b0 = ld16(Bp + o0);
-            const u32x4 r1 = ld16(R + o1), g1 = ld16(G + o1), b1 = ld16(Bp + o1);
+            const u32x4 r0 = ld16<IAK_NT_GRAY_LD>(R + o0), g0 = ld16<IAK_NT_GRAY_LD>(G + o0), b0 = ld16<IAK_NT_GRAY_LD>(Bp + o0);
+            const u32x4 r1 = ld16<IAK_NT_GRAY_LD>(R + o1), g1 = ld16<IAK_NT_GRAY_LD>(G + o1), b1 = ld16<IAK_NT_GRAY_LD>(Bp + o1);
             u32x4 y0, y1;
 #pragma unroll
             for (int w = 0; w < 4; w++) y0[w] = gray4<METHOD>(r0[w], g0[w], b0[w]);
-            st16(dst + o0, y0);
+            st16<IAK_NT_GRAY_ST>(dst + o0, y0);
             if (HIST) {
 #pragma unroll
                 for (int w = 0; w < 4; w++) hist_add4(sh, y0[w], col);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(GRAY_THREADS) void gray_kernel(const uint8_t *__res
             if (two) {
 #pragma unroll
                 for (int w = 0; w < 4; w++) y1[w] = gray4<METHOD>(r1[w], g1[w], b1[w]);
-                st16(dst + o1, y1);
+                st16<IAK_NT_GRAY_ST>(dst + o1, y1);
                 if (HIST) {
 #pragma unroll
                     for (int w = 0; w < 4; w++) hist_add4(sh, y1[w], col);

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void generic_edge_kernel(const uint8_t *__rest
 // min/med/max, 16-bit packed arithmetic, byte-wise SWAR and dot products wherever the
 // arithmetic allows, and 8 pixels per lane to keep a three-row window near 30 registers.
 __device__ __forceinline__ Raw16 load_raw(__amdgpu_buffer_rsrc_t rsrc, int voffset) {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, 0, 0);
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, 0, IAK_NT_STENCIL_LD ? 2 : 0);
     Raw16 r;
     r.d[0] = v[0]; r.d[1] = v[1]; r.d[2] = v[2]; r.d[3] = v[3];
     return r;
@@ -255,8 +255,7 @@ __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict
                 if (col0 == 0) o[0] &= 0xffffff00u;  // col < 1; col > W-1 cannot happen
             }
             if (row < H) {
-                uint2 v = make_uint2(o[0], o[1]);
-                *reinterpret_cast<uint2 *>(dst + (long long)row * W + col0) = v;
+                st8<IAK_NT_STENCIL_ST>(dst + (long long)row * W + col0, o[0], o[1]);
             }
             up = mid;
             mid = dn;

@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libiak.so")
+# IAK_LIBRARY names another build of the same library (used to compare builds)
+LIB_PATH = os.environ.get("IAK_LIBRARY") or os.path.join(_HERE, "lib", "libiak.so")
 
 IAK_E_ARG, IAK_E_UNSUPPORTED, IAK_E_TOO_LARGE = -1, -2, -3
 IAK_LINEAR_CLAMP, IAK_LINEAR_AVERAGE = 0, 1
@@ -61,7 +62,7 @@ SIGNATURES = {
     "iak_pipeline_set_lanes": [_vp, _i],
     "iak_pipeline_timed_images": [_vp],
     "iak_pipeline_set_timing": [_vp, _i],
-    "iak_pipeline_timings": [_vp, _i, _vp, _vp, _vp, _i],
+    "iak_pipeline_timings": [_vp, _i, _vp, _vp, _vp, _vp, _i],
 }
 _RESTYPE = {"iak_error_string": C.c_char_p}
 

@@ -129,18 +129,20 @@ class Pipeline:
         cap = 64
         names = (C.c_char_p * cap)()
         ab = (C.c_longlong * cap)()
-        n = _l.load().iak_pipeline_timings(self._h, 0, None, names, ab, cap)
+        n = _l.load().iak_pipeline_timings(self._h, 0, None, None, names, ab, cap)
         if n < 0:
             raise _l.IakError(n, "iak_pipeline_timings")
         return [(names[i].decode(), int(ab[i])) for i in range(n)]
 
     def timings(self, slot=0):
-        """[(name, ms, algorithmic bytes per pixel)] of the timed run in `slot` (synchronises)."""
+        """[(name, ms, algorithmic bytes per pixel, ms of the group's image kernel alone)] of the
+        timed run in `slot` (synchronises)."""
         cap = 64
         ms = (C.c_float * cap)()
+        main = (C.c_float * cap)()
         names = (C.c_char_p * cap)()
         ab = (C.c_longlong * cap)()
-        n = _l.load().iak_pipeline_timings(self._h, int(slot), ms, names, ab, cap)
+        n = _l.load().iak_pipeline_timings(self._h, int(slot), ms, main, names, ab, cap)
         if n < 0:
             raise _l.IakError(n, "iak_pipeline_timings")
-        return [(names[i].decode(), float(ms[i]), int(ab[i])) for i in range(n)]
+        return [(names[i].decode(), float(ms[i]), int(ab[i]), float(main[i])) for i in range(n)]

@@ -218,11 +218,13 @@ int iak_pipeline_timed_images(iak_pipeline *p);
  * (0 disables; this call allocates events, runs do not); run number r then records one event
  * between launch groups into set r % slots, counting runs from the set_timing call.
  * timings(p, slot, ...) waits for that set's last event and fills up to cap entries:
- * ms[] (may be NULL to query names only), names[], alg_bytes_per_px[] (the stage-wise
- * compulsory traffic of the operations in the group).  Returns the number of groups, or a
- * negative error. */
+ * ms[] (the whole group), main_ms[] (the group's image kernel alone, without the small helper
+ * launch some groups have: the table prologue of a per-pixel run, the dataset-histogram
+ * accumulation after the grayscale pass), names[], alg_bytes_per_px[] (the stage-wise
+ * compulsory traffic of the operations in the group).  ms and main_ms may both be NULL to
+ * query names only.  Returns the number of groups, or a negative error. */
 int iak_pipeline_set_timing(iak_pipeline *p, int slots);
-int iak_pipeline_timings(iak_pipeline *p, int slot, float *ms, const char **names,
+int iak_pipeline_timings(iak_pipeline *p, int slot, float *ms, float *main_ms, const char **names,
                          long long *alg_bytes_per_px, int cap);
 
 #ifdef __cplusplus
