@@ -7,13 +7,13 @@
 
 namespace iak {
 
-enum { C_EQUALIZE = 1, C_OTSU = 2, C_CONST_LUT = 3, C_GAUSS = 4, C_SP = 5 };
+enum { C_EQUALIZE = 1, C_OTSU = 2, C_CONST_LUT = 3, C_GAUSS = 4, C_SP = 5, C_KMEANS = 6 };
 #define CHAIN_MAX 6
 
 struct ChainStage {
     int type;
     float mean, stddev;    // C_GAUSS
-    const uint8_t *plane;  // C_GAUSS: rv plane, C_SP: code plane
+    const uint8_t *plane;  // C_GAUSS: rv plane, C_SP: code plane, C_KMEANS: int32 initial centroids [B][2]
     int lut_slot;          // C_CONST_LUT: index into ChainDesc::const_lut
 };
 struct ChainDesc {

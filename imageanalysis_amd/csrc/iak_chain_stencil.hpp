@@ -1,0 +1,156 @@
+// The kernel that runs a chain of per-pixel operations and the 3x3 stencil behind it in one
+// pass, staging the chain's output in LDS.  Shared by the pipeline executor and the feature
+// extraction entry point.
+#pragma once
+#include "iak_chain.hpp"
+#include "iak_stencil_ops.hpp"
+
+namespace iak {
+
+// number of bytes of x equal to 0xff
+__device__ __forceinline__ uint32_t bytes_equal_255(uint32_t x) {
+    const uint32_t m = x & 0x80808080u & ((x & 0x7f7f7f7fu) + 0x01010101u);
+    return (uint32_t)__builtin_popcount(m);
+}
+
+// ---------------------------------------------------------------------------------------
+// Chain fused into the following 3x3 stencil.  A workgroup stages a tile of the CHAIN'S OUTPUT
+// in LDS -- (TH+2) rows x (TW+32) columns on the flat view of the image, every pixel pushed
+// through the chain exactly once (plus the thin halo) -- and then runs the stencil operator of
+// iak_stencil_ops.hpp on rows read from LDS instead of from memory.  The intermediate image
+// is never written: one read of the chain's input and one write of the stencil's output.
+// Pixels outside the image are staged as 0 (the reference's out-of-range taps), not as
+// chain(0).
+// ---------------------------------------------------------------------------------------
+#define CS_THREADS 512
+// COUNT255: nothing is stored; the workgroup adds the number of output pixels equal to 255 to
+// counts[b] (the "perimeter" of imageMachineLearning.cu:362-366 without writing the edge image).
+template <class Op, bool COUNT255 = false>
+__global__ __launch_bounds__(CS_THREADS) void chain_stencil8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                             int W, int H, long long in_stride, long long out_stride,
+                                                             ChainDesc d, const uint16_t *__restrict__ tables, int TW,
+                                                             int TH, int tiles_x, Op op,
+                                                             uint32_t *__restrict__ counts = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int pitch = TW + 32;
+    const int tile_bytes = (TH + 2) * pitch;
+    uint8_t *tile = smem;
+    ChainTables &t = *reinterpret_cast<ChainTables *>(smem + tile_bytes);  // tile_bytes is a multiple of 16
+    const int b = blockIdx.y;
+    chain_load_tables(t, d, tables + (long long)b * CHAIN_MAX * 256);
+    const uint8_t *src = in + (long long)b * in_stride;
+    uint8_t *dst = out + (long long)b * out_stride;
+    const long long N = (long long)W * H;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+
+    // phase 1: stage chain(input) for rows y0-1 .. y0+TH, columns x0-16 .. x0+TW+15
+    const int cpr = pitch >> 4;  // 16-byte chunks per tile row
+    const int nchunks = (TH + 2) * cpr;
+    for (int c = threadIdx.x; c < nchunks; c += 2 * CS_THREADS) {
+        const int c1 = c + CS_THREADS;
+        const int r0 = c / cpr, k0 = c - r0 * cpr;
+        const int r1 = c1 / cpr, k1 = c1 - r1 * cpr;
+        const long long f0 = (long long)(y0 - 1 + r0) * W + (x0 - 16 + 16 * k0);
+        const long long f1 = (long long)(y0 - 1 + r1) * W + (x0 - 16 + 16 * k1);
+        const bool ok0 = f0 >= 0 && f0 < N;  // W % 16 == 0: a chunk is wholly inside or outside
+        const bool ok1 = c1 < nchunks && f1 >= 0 && f1 < N;
+        const long long g0 = ok0 ? f0 : 0, g1 = ok1 ? f1 : 0;
+        u32x4 v0 = ld16<IAK_NT_CHAIN_LD>(src + g0);
+        u32x4 v1 = ld16<IAK_NT_CHAIN_LD>(src + g1);
+        v0 = chain_apply16(v0, g0, d, t);
+        v1 = chain_apply16(v1, g1, d, t);
+        const u32x4 zero = {0, 0, 0, 0};
+        *reinterpret_cast<u32x4 *>(tile + r0 * pitch + 16 * k0) = ok0 ? v0 : zero;
+        if (c1 < nchunks) *reinterpret_cast<u32x4 *>(tile + r1 * pitch + 16 * k1) = ok1 ? v1 : zero;
+    }
+    __syncthreads();
+
+    // phase 2: the stencil on 8-pixel chunks x groups of 8 rows, rows coming from the tile
+    const int cols = TW >> 3;
+    const int items = cols * (TH >> 3);
+    uint32_t n255 = 0;
+    for (int it = threadIdx.x; it < items; it += CS_THREADS) {
+        const int rg = it / cols, cx = it - rg * cols;
+        const int col0 = x0 + (cx << 3);
+        const int yb = y0 + (rg << 3);
+        if (col0 >= W || yb >= H) continue;
+        const uint8_t *base = tile + (rg << 3) * pitch + ((cx << 3) + 12);  // column col0-4 of tile row 8*rg
+        Raw16 raw[10];
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(base + r * pitch);
+            raw[r].d[0] = q[0]; raw[r].d[1] = q[1]; raw[r].d[2] = q[2]; raw[r].d[3] = q[3];
+        }
+        typename Op::Row up, mid, dn;
+        op.prepare(raw[0], yb - 1, col0, W, H, up);
+        op.prepare(raw[1], yb, col0, W, H, mid);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int row = yb + r;
+            op.prepare(raw[r + 2], row + 1, col0, W, H, dn);
+            uint32_t o[2];
+            op.compute(up, mid, dn, o);
+            if (Op::kBorderZero) {
+                if (row < 1) o[0] = o[1] = 0;
+                if (col0 == 0) o[0] &= 0xffffff00u;
+            }
+            if (COUNT255) {
+                if (row < H) n255 += bytes_equal_255(o[0]) + bytes_equal_255(o[1]);
+            } else {
+                if (row < H) st8<IAK_NT_STENCIL_ST>(dst + (long long)row * W + col0, o[0], o[1]);
+            }
+            up = mid;
+            mid = dn;
+        }
+    }
+    if (COUNT255) {
+        for (int o = 32; o > 0; o >>= 1) n255 += __shfl_down(n255, o);
+        if ((threadIdx.x & 63) == 0 && n255) atomicAdd(&counts[b], n255);
+    }
+}
+
+struct TileGeom {
+    int TW, TH, tiles_x, tiles_y;
+    size_t lds;
+};
+
+// Tile: as wide as the image up to 1024 columns; height 8k rows with the tile under 40 KiB
+// (four workgroups per CU) and k picked so that (TW/8)*k work items fill the workgroup's lanes evenly.
+static TileGeom tile_geometry(int W, int H) {
+    TileGeom g;
+    g.TW = W <= 1024 ? W : 1024;
+    g.tiles_x = (W + g.TW - 1) / g.TW;
+    const int pitch = g.TW + 32;
+    int kmax = ((40960 / pitch) - 2) / 8;
+    if (kmax < 1) kmax = 1;
+    if (kmax > 8) kmax = 8;
+    int best = kmax;
+    double best_eff = -1;
+    for (int k = kmax; k >= 1 && k >= kmax - 3; k--) {
+        const int items = (g.TW / 8) * k;
+        const double eff = (double)items / ((double)CS_THREADS * ((items + CS_THREADS - 1) / CS_THREADS));
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
+    }
+    g.TH = 8 * best;
+    g.tiles_y = (H + g.TH - 1) / g.TH;
+    g.lds = (size_t)(g.TH + 2) * pitch + sizeof(ChainTables);
+    return g;
+}
+
+// in: B images at stride in_stride, 16-byte aligned; W % 16 == 0; out 8-byte aligned (or, with
+// COUNT255, counts[B] zeroed by the caller).  tables: [B][CHAIN_MAX][256] as chain_prep_kernel
+// or any other producer lays them out.
+template <class Op, bool COUNT255 = false>
+static int launch_chain_stencil(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+                                long long out_stride, const ChainDesc &d, const uint16_t *tables, const Op &op,
+                                hipStream_t s, uint32_t *counts = nullptr) {
+    const TileGeom g = tile_geometry(W, H);
+    hipLaunchKernelGGL((chain_stencil8_kernel<Op, COUNT255>), dim3(g.tiles_x * g.tiles_y, B), dim3(CS_THREADS), g.lds, s, in,
+                       out, W, H, in_stride, out_stride, d, tables, g.TW, g.TH, g.tiles_x, op, counts);
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
+
+}  // namespace iak

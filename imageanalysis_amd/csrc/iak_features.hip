@@ -1,0 +1,263 @@
+// Feature extraction and k-means thresholding for batches, as histogram arithmetic.
+//
+// featureExtraction (imageMachineLearning.cu:393-415) makes five image passes per image
+// (statistics, Otsu threshold, histogram of the mask, compass filter, histogram of the edges,
+// histogram of the image).  Everything but the edge count is a function of the image's
+// 256-bin histogram; the edge count needs the compass filter of the Otsu mask, which is
+// computed here straight from the image (mask staged in LDS) and counted without being stored:
+// one histogram pass (skipped when the caller has the histogram) plus one read of the image.
+//
+// kMeansThresholding (imageAnalysis.cu:281-379): a pixel's label depends on its value only,
+// so each iteration's class sums and counts come from the histogram; the image is touched by
+// one table pass at the end.
+#include "iak_chain_stencil.hpp"
+#include "iak_device_fns.hpp"
+#include "iak_common.hpp"
+
+#include <cstring>
+#include <vector>
+
+namespace iak {
+
+#define FEAT_N 7
+
+// One lane per image.  features[b] = {mean, std, area, (perimeter: later), mode, rangeMin, rangeMax};
+// tables[b][0][v] = Otsu mask value of v; counts[b] = 0.
+__global__ __launch_bounds__(64) void features_stats_kernel(const uint32_t *__restrict__ hist, int numPixels, int B,
+                                                            float *__restrict__ features,
+                                                            uint16_t *__restrict__ tables, uint32_t *__restrict__ counts,
+                                                            int32_t *__restrict__ thr_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t *h = hist + (long long)b * 256;
+    float mean, sd;
+    mean_std_from_hist(h, numPixels, &mean, &sd);                // imageMachineLearning.cu:396
+    const int thr = otsu_threshold_from_hist(h, numPixels);     // :399 -> imageAnalysis.cu:255-277
+    long long above = 0;                                          // pixels the mask sets to 255
+    for (int v = 1; v < 256; v++)
+        if (v > thr) above += h[v];
+    const long long rest = (long long)numPixels - above;
+    const long long area = above < rest ? above : rest;          // :353-360
+    int maxVal = 0, mode = -1;                                    // :341-351 (bin 0 is always empty)
+    for (int i = 1; i < 256; i++)
+        if (maxVal < (int)h[i]) {
+            maxVal = (int)h[i];
+            mode = i;
+        }
+    int rmin = -1, rmax = -1;                                     // :379-390
+    for (int i = 1; i < 256; i++)
+        if (h[i] != 0 && rmin == -1) rmin = i;
+    for (int i = 255; i >= 1; i--)
+        if (h[i] != 0 && rmin != -1 && rmax == -1) rmax = i;
+    float *f = features + (long long)b * FEAT_N;
+    f[0] = mean;
+    f[1] = sd;
+    f[2] = (float)(int)area;
+    f[4] = (float)mode;
+    f[5] = (float)rmin;
+    f[6] = (float)rmax;
+    uint16_t *t = tables + (long long)b * CHAIN_MAX * 256;
+    for (int v = 0; v < 256; v++) t[v] = v > thr ? 255 : 0;      // thresholdImage (imageAnalysis.cu:207-216)
+    counts[b] = 0;
+    thr_out[b] = thr;
+}
+
+// perimeter = number of 255s in the compass image of the mask (:362-366), from the counter
+// of the fused pass or from that image's histogram
+__global__ void features_perimeter_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ edge_hist,
+                                          float *__restrict__ features, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) features[(long long)b * FEAT_N + 3] = (float)(int)(counts ? counts[b] : edge_hist[(long long)b * 256 + 255]);
+}
+
+// ---- kMeansThresholding (imageAnalysis.cu:281-379), k = 2, on the histogram ------------------
+// One wave per image, four bins per lane.  Labels: 0 = nearer to centroid 1 (the reference's
+// inverted test, :298-302); class sums accumulate as unsigned int (wrapping like the
+// reference's, :323), counts as int; new centroid = (uchar)floorf(sum / (float)count), NaN
+// (empty class) -> 0; stop when no centroid changes or after 100 rounds (:376).  The map is
+// that of the LAST labelling (:339-349).
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__global__ __launch_bounds__(64) void kmeans2_kernel(const uint32_t *__restrict__ hist, int numPixels, int B,
+                                                      const int32_t *__restrict__ init, int32_t *__restrict__ map,
+                                                      int32_t *__restrict__ iterations) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    uint32_t h[4];
+    uint32_t nonzero = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int v = lane * 4 + j;
+        h[j] = v == 0 ? 0u : hist[(long long)b * 256 + v];
+        nonzero += h[j];
+    }
+    nonzero = wave_sum(nonzero);
+    if (lane == 0) h[0] = (uint32_t)numPixels - nonzero;  // the histogram leaves the zeros out
+    int c0 = (uint8_t)init[2 * b], c1 = (uint8_t)init[2 * b + 1];
+    int count = 0;
+    bool changed;
+    uint32_t lab = 0;  // bit j = label of bin lane*4+j
+    do {
+        uint32_t s0 = 0, s1 = 0, n0 = 0, n1 = 0;
+        lab = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int v = lane * 4 + j;
+            const bool one = !(abs(c0 - v) > abs(c1 - v));
+            lab |= (one ? 1u : 0u) << j;
+            if (one) { s1 += (uint32_t)v * h[j]; n1 += h[j]; }
+            else { s0 += (uint32_t)v * h[j]; n0 += h[j]; }
+        }
+        s0 = wave_sum(s0); s1 = wave_sum(s1); n0 = wave_sum(n0); n1 = wave_sum(n1);
+        const int m0 = (int)f2u8(floorf((float)s0 / (float)(int)n0));
+        const int m1 = (int)f2u8(floorf((float)s1 / (float)(int)n1));
+        count++;
+        changed = (c0 != m0) || (c1 != m1);
+        c0 = m0;
+        c1 = m1;
+    } while (changed && count < 100);
+#pragma unroll
+    for (int j = 0; j < 4; j++) map[(long long)b * 256 + lane * 4 + j] = ((lab >> j) & 1u) ? 255 : 0;
+    if (iterations && lane == 0) iterations[b] = count;
+}
+
+// ---- glibc's rand() (TYPE_3 additive feedback, x[i] = x[i-3] + x[i-31], output x >> 1) --------
+// The reference seeds its k-means centroids from libc rand() without ever calling srand
+// (imageAnalysis.cu:39-41,359-361), so the centroids of the n-th image are a fixed function
+// of n.  state: 34 words of history + a position; one lane draws sequentially.
+#define GR_WORDS 35
+// Draws are consumed image by image, and within an image operation by operation, two each;
+// they are stored operation-major: out[(op * images + image) * 2 + j].
+__global__ void glibc_rand_centroids_kernel(uint32_t *__restrict__ state, int images, int ops_per_image,
+                                            int32_t *__restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int count = images * ops_per_image * 2;
+    uint32_t r[34];
+    for (int i = 0; i < 34; i++) r[i] = state[i];
+    uint32_t pos = state[34];  // index of the oldest word: history is r[pos], r[pos+1], ... (mod 34)
+    for (int i = 0; i < count; i++) {
+        // newest = x[n-3] + x[n-31]; with 34 words kept, x[n-34] sits at pos
+        const uint32_t x = r[(pos + 31) % 34] + r[(pos + 3) % 34];
+        r[pos] = x;
+        pos = (pos + 1) % 34;
+        const int draw = (int)(x >> 1);
+        const int image = i / (2 * ops_per_image), op = (i >> 1) % ops_per_image;
+        out[((long long)op * images + image) * 2 + (i & 1)] = draw / (2147483647 / 257 + 1);  // random(0, 256), imageAnalysis.cu:39-41
+    }
+    for (int i = 0; i < 34; i++) state[i] = r[i];
+    state[34] = pos;
+}
+
+}  // namespace iak
+
+using namespace iak;
+
+static void glibc_rand_initial_state(unsigned seed, uint32_t st[GR_WORDS]) {
+    // srandom_r for TYPE_3: 31 words by the Lehmer recurrence, three wrapped copies, 310 discards
+    std::vector<uint32_t> x(344);
+    int32_t w = seed == 0 ? 1 : (int32_t)seed;
+    x[0] = (uint32_t)w;
+    for (int i = 1; i < 31; i++) {
+        const long long hi = w / 127773, lo = w % 127773;
+        long long word = 16807 * lo - 2836 * hi;
+        if (word < 0) word += 2147483647;
+        w = (int32_t)word;
+        x[i] = (uint32_t)w;
+    }
+    for (int i = 31; i < 34; i++) x[i] = x[i - 31];
+    for (int i = 34; i < 344; i++) x[i] = x[i - 31] + x[i - 3];
+    for (int i = 0; i < 34; i++) st[i] = x[310 + i];  // the last 34 words, oldest first
+    st[34] = 0;
+}
+
+extern "C" {
+
+long long iak_features_workspace_bytes(int W, int H, int B) {
+    if (W <= 0 || H <= 0 || B <= 0) return IAK_E_ARG;
+    const long long N = (long long)W * H;
+    long long bytes = 0;
+    bytes += (long long)B * 256 * 4;              // histogram of the image
+    bytes += (long long)B * CHAIN_MAX * 256 * 2;  // mask table
+    bytes += (long long)B * 4 * 2;                // edge counts, thresholds
+    bytes = (bytes + 255) & ~255LL;
+    if (W % 16 != 0) bytes += 2 * (((long long)B * N + 255) & ~255LL) + (long long)B * 256 * 4;  // mask, edges, their histogram
+    return bytes;
+}
+
+int iak_features(const uint8_t *img, int W, int H, int B, long long stride, const uint32_t *hist, float *features,
+                 void *workspace, void *stream) {
+    if (!img || !features || !workspace || W <= 0 || H <= 0 || B <= 0) return IAK_E_ARG;
+    const long long N = (long long)W * H;
+    if (stride < N || N >= (1LL << 31)) return IAK_E_ARG;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return IAK_E_ARG;
+    hipStream_t s = as_stream(stream);
+    uint8_t *ws = static_cast<uint8_t *>(workspace);
+    uint32_t *own_hist = reinterpret_cast<uint32_t *>(ws);
+    uint16_t *tables = reinterpret_cast<uint16_t *>(ws + (size_t)B * 256 * 4);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(ws + (size_t)B * 256 * 4 + (size_t)B * CHAIN_MAX * 256 * 2);
+    int32_t *thr = reinterpret_cast<int32_t *>(counts + B);
+    size_t head = (size_t)B * 256 * 4 + (size_t)B * CHAIN_MAX * 256 * 2 + (size_t)B * 8;
+    head = (head + 255) & ~(size_t)255;
+    int rc;
+    if (!hist) {
+        if ((rc = iak_hist(img, own_hist, N, B, stride, stream))) return rc;
+        hist = own_hist;
+    }
+    hipLaunchKernelGGL(features_stats_kernel, dim3((B + 63) / 64), dim3(64), 0, s, hist, (int)N, B, features, tables, counts,
+                       thr);
+    IAK_LAUNCH_CHECK();
+    if (W % 16 == 0 && aligned16(img) && stride % 16 == 0) {
+        ChainDesc d;
+        memset(&d, 0, sizeof d);
+        d.n = 1;
+        d.st[0].type = C_OTSU;
+        if ((rc = launch_chain_stencil<Compass8, true>(img, nullptr, W, H, B, stride, 0, d, tables, Compass8(), s, counts)))
+            return rc;
+        hipLaunchKernelGGL(features_perimeter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, counts, (const uint32_t *)nullptr,
+                           features, B);
+    } else {
+        // any other shape: the three passes of the reference, on workspace images
+        const size_t img_bytes = ((size_t)B * (size_t)N + 255) & ~(size_t)255;
+        uint8_t *mask = ws + head, *edges = mask + img_bytes;
+        uint32_t *edge_hist = reinterpret_cast<uint32_t *>(edges + img_bytes);
+        if ((rc = iak_threshold_per_image(img, mask, N, B, stride, N, thr, stream))) return rc;
+        if ((rc = iak_compass(mask, edges, W, H, B, N, N, stream))) return rc;
+        if ((rc = iak_hist(edges, edge_hist, N, B, N, stream))) return rc;
+        hipLaunchKernelGGL(features_perimeter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const uint32_t *)nullptr,
+                           edge_hist, features, B);
+    }
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
+int iak_kmeans2_map(const uint32_t *hist, int numPixels, int B, const int32_t *init_centroids, int32_t *map,
+                    int32_t *iterations, void *stream) {
+    if (!hist || !init_centroids || !map || numPixels <= 0 || B <= 0) return IAK_E_ARG;
+    hipLaunchKernelGGL(kmeans2_kernel, dim3(B), dim3(64), 0, as_stream(stream), hist, numPixels, B, init_centroids, map,
+                       iterations);
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
+int iak_glibc_rand_seed(uint32_t *state, unsigned seed, void *stream) {
+    if (!state) return IAK_E_ARG;
+    uint32_t st[GR_WORDS];
+    glibc_rand_initial_state(seed, st);
+    hipStream_t s = as_stream(stream);
+    IAK_HIP(hipMemcpyAsync(state, st, sizeof st, hipMemcpyHostToDevice, s));
+    IAK_HIP(hipStreamSynchronize(s));  // st is a stack array
+    return 0;
+}
+
+int iak_glibc_rand_centroids(uint32_t *state, int images, int ops_per_image, int32_t *out, void *stream) {
+    if (!state || !out || images < 0 || ops_per_image < 0) return IAK_E_ARG;
+    if (images == 0 || ops_per_image == 0) return 0;
+    if ((long long)images * ops_per_image > (1 << 28)) return IAK_E_TOO_LARGE;
+    hipLaunchKernelGGL(glibc_rand_centroids_kernel, dim3(1), dim3(64), 0, as_stream(stream), state, images, ops_per_image,
+                       out);
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -13,6 +13,7 @@
 #include "iak_common.hpp"
 #include "iak_device_fns.hpp"
 #include "iak_chain.hpp"
+#include "iak_chain_stencil.hpp"
 #include "iak_stencil_ops.hpp"
 
 #include <new>
@@ -140,6 +141,29 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *__restr
             }
             __syncthreads();
             lut = (v > thr_s) ? 255u : 0u;
+        } else if (st.type == C_KMEANS) {
+            // kMeansThresholding (imageAnalysis.cu:281-379) on the histogram; lane v = value v.
+            // Label 1 = not nearer to centroid 1 (:298-302); class sums wrap as unsigned int.
+            const long long nz = block_sum_ll((long long)hv, red);
+            const uint32_t cnt = (v == 0) ? (uint32_t)((long long)numPixels - nz) : hv;
+            const int32_t *ini = reinterpret_cast<const int32_t *>(st.plane) + 2 * (long long)b;
+            int c0 = (uint8_t)ini[0], c1 = (uint8_t)ini[1];
+            int rounds = 0;
+            bool changed, one;
+            do {
+                one = !(abs(c0 - v) > abs(c1 - v));
+                const uint32_t s0 = (uint32_t)block_sum_ll(one ? 0 : (long long)((uint32_t)v * cnt), red);
+                const uint32_t s1 = (uint32_t)block_sum_ll(one ? (long long)((uint32_t)v * cnt) : 0, red);
+                const int n0 = (int)block_sum_ll(one ? 0 : (long long)cnt, red);
+                const int n1 = (int)block_sum_ll(one ? (long long)cnt : 0, red);
+                const int m0 = (int)f2u8(floorf((float)s0 / (float)n0));  // :332; empty class: NaN -> 0
+                const int m1 = (int)f2u8(floorf((float)s1 / (float)n1));
+                rounds++;
+                changed = (c0 != m0) || (c1 != m1);
+                c0 = m0;
+                c1 = m1;
+            } while (changed && rounds < 100);
+            lut = one ? 255u : 0u;
         } else {
             lut = d.const_lut[st.lut_slot][v];
         }
@@ -188,130 +212,6 @@ __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restr
     for (long long x = scalar_from + tid; x < N; x += nthreads) dst[x] = (uint8_t)chain_apply1(src[x], x, d, t);
 }
 
-// ---------------------------------------------------------------------------------------
-// Chain fused into the following 3x3 stencil.  A workgroup stages a tile of the CHAIN'S OUTPUT
-// in LDS -- (TH+2) rows x (TW+32) columns on the flat view of the image, every pixel pushed
-// through the chain exactly once (plus the thin halo) -- and then runs the stencil operator of
-// iak_stencil_ops.hpp on rows read from LDS instead of from memory.  The intermediate image
-// is never written: one read of the chain's input and one write of the stencil's output.
-// Pixels outside the image are staged as 0 (the reference's out-of-range taps), not as
-// chain(0).
-// ---------------------------------------------------------------------------------------
-#define CS_THREADS 512
-template <class Op>
-__global__ __launch_bounds__(CS_THREADS) void chain_stencil8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                                             int W, int H, long long in_stride, long long out_stride,
-                                                             ChainDesc d, const uint16_t *__restrict__ tables, int TW,
-                                                             int TH, int tiles_x, Op op) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int pitch = TW + 32;
-    const int tile_bytes = (TH + 2) * pitch;
-    uint8_t *tile = smem;
-    ChainTables &t = *reinterpret_cast<ChainTables *>(smem + tile_bytes);  // tile_bytes is a multiple of 16
-    const int b = blockIdx.y;
-    chain_load_tables(t, d, tables + (long long)b * CHAIN_MAX * 256);
-    const uint8_t *src = in + (long long)b * in_stride;
-    uint8_t *dst = out + (long long)b * out_stride;
-    const long long N = (long long)W * H;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH;
-
-    // phase 1: stage chain(input) for rows y0-1 .. y0+TH, columns x0-16 .. x0+TW+15
-    const int cpr = pitch >> 4;  // 16-byte chunks per tile row
-    const int nchunks = (TH + 2) * cpr;
-    for (int c = threadIdx.x; c < nchunks; c += 2 * CS_THREADS) {
-        const int c1 = c + CS_THREADS;
-        const int r0 = c / cpr, k0 = c - r0 * cpr;
-        const int r1 = c1 / cpr, k1 = c1 - r1 * cpr;
-        const long long f0 = (long long)(y0 - 1 + r0) * W + (x0 - 16 + 16 * k0);
-        const long long f1 = (long long)(y0 - 1 + r1) * W + (x0 - 16 + 16 * k1);
-        const bool ok0 = f0 >= 0 && f0 < N;  // W % 16 == 0: a chunk is wholly inside or outside
-        const bool ok1 = c1 < nchunks && f1 >= 0 && f1 < N;
-        const long long g0 = ok0 ? f0 : 0, g1 = ok1 ? f1 : 0;
-        u32x4 v0 = ld16<IAK_NT_CHAIN_LD>(src + g0);
-        u32x4 v1 = ld16<IAK_NT_CHAIN_LD>(src + g1);
-        v0 = chain_apply16(v0, g0, d, t);
-        v1 = chain_apply16(v1, g1, d, t);
-        const u32x4 zero = {0, 0, 0, 0};
-        *reinterpret_cast<u32x4 *>(tile + r0 * pitch + 16 * k0) = ok0 ? v0 : zero;
-        if (c1 < nchunks) *reinterpret_cast<u32x4 *>(tile + r1 * pitch + 16 * k1) = ok1 ? v1 : zero;
-    }
-    __syncthreads();
-
-    // phase 2: the stencil on 8-pixel chunks x groups of 8 rows, rows coming from the tile
-    const int cols = TW >> 3;
-    const int items = cols * (TH >> 3);
-    for (int it = threadIdx.x; it < items; it += CS_THREADS) {
-        const int rg = it / cols, cx = it - rg * cols;
-        const int col0 = x0 + (cx << 3);
-        const int yb = y0 + (rg << 3);
-        if (col0 >= W || yb >= H) continue;
-        const uint8_t *base = tile + (rg << 3) * pitch + ((cx << 3) + 12);  // column col0-4 of tile row 8*rg
-        Raw16 raw[10];
-#pragma unroll
-        for (int r = 0; r < 10; r++) {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(base + r * pitch);
-            raw[r].d[0] = q[0]; raw[r].d[1] = q[1]; raw[r].d[2] = q[2]; raw[r].d[3] = q[3];
-        }
-        typename Op::Row up, mid, dn;
-        op.prepare(raw[0], yb - 1, col0, W, H, up);
-        op.prepare(raw[1], yb, col0, W, H, mid);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int row = yb + r;
-            op.prepare(raw[r + 2], row + 1, col0, W, H, dn);
-            uint32_t o[2];
-            op.compute(up, mid, dn, o);
-            if (Op::kBorderZero) {
-                if (row < 1) o[0] = o[1] = 0;
-                if (col0 == 0) o[0] &= 0xffffff00u;
-            }
-            if (row < H) st8<IAK_NT_STENCIL_ST>(dst + (long long)row * W + col0, o[0], o[1]);
-            up = mid;
-            mid = dn;
-        }
-    }
-}
-
-struct TileGeom {
-    int TW, TH, tiles_x, tiles_y;
-    size_t lds;
-};
-
-// Tile: as wide as the image up to 1024 columns; height 8k rows with the tile under 40 KiB
-// (four workgroups per CU) and k picked so that (TW/8)*k work items fill the workgroup's lanes evenly.
-static TileGeom tile_geometry(int W, int H) {
-    TileGeom g;
-    g.TW = W <= 1024 ? W : 1024;
-    g.tiles_x = (W + g.TW - 1) / g.TW;
-    const int pitch = g.TW + 32;
-    int kmax = ((40960 / pitch) - 2) / 8;
-    if (kmax < 1) kmax = 1;
-    if (kmax > 8) kmax = 8;
-    int best = kmax;
-    double best_eff = -1;
-    for (int k = kmax; k >= 1 && k >= kmax - 3; k--) {
-        const int items = (g.TW / 8) * k;
-        const double eff = (double)items / ((double)CS_THREADS * ((items + CS_THREADS - 1) / CS_THREADS));
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = k; }
-    }
-    g.TH = 8 * best;
-    g.tiles_y = (H + g.TH - 1) / g.TH;
-    g.lds = (size_t)(g.TH + 2) * pitch + sizeof(ChainTables);
-    return g;
-}
-
-template <class Op>
-static int launch_chain_stencil(const uint8_t *in, uint8_t *out, int W, int H, int B, const ChainDesc &d,
-                                const uint16_t *tables, const Op &op, hipStream_t s) {
-    const TileGeom g = tile_geometry(W, H);
-    const long long N = (long long)W * H;
-    hipLaunchKernelGGL((chain_stencil8_kernel<Op>), dim3(g.tiles_x * g.tiles_y, B), dim3(CS_THREADS), g.lds, s, in, out, W, H, N,
-                       N, d, tables, g.TW, g.TH, g.tiles_x, op);
-    IAK_LAUNCH_CHECK();
-    return 0;
-}
-
 // dataset histogram: sum[v] += sum_b hist[b][v]; each workgroup folds 8 images
 #define ACC_IMAGES 8
 __global__ __launch_bounds__(256) void hist_accumulate_kernel(const uint32_t *__restrict__ hist, int B,
@@ -334,11 +234,12 @@ namespace {
 
 struct OpCopy {
     iak_op op;
+    int kmeans_index = -1;  // IAK_OP_KMEANS: its number among the pipeline's k-means operations
     std::vector<float> f;
     std::vector<int> i;
 };
 
-enum GroupKind { G_GRAYHIST, G_HIST, G_CHAIN, G_OP, G_CHAIN_OP };
+enum GroupKind { G_GRAYHIST, G_HIST, G_CHAIN, G_OP, G_CHAIN_OP, G_FEATURES };
 
 struct Group {
     GroupKind kind;
@@ -366,24 +267,26 @@ bool is_fusable_stencil(const iak_op &o) {
 
 bool is_pointwise(int t) {
     return t == IAK_OP_EQUALIZE || t == IAK_OP_GAUSS || t == IAK_OP_SALT_PEPPER || t == IAK_OP_THRESHOLD ||
-           t == IAK_OP_OTSU || t == IAK_OP_QUANTIZE;
+           t == IAK_OP_OTSU || t == IAK_OP_QUANTIZE || t == IAK_OP_KMEANS;
 }
 bool needs_hist(const iak_op &o) {
-    return o.type == IAK_OP_EQUALIZE || o.type == IAK_OP_OTSU ||
+    return o.type == IAK_OP_EQUALIZE || o.type == IAK_OP_OTSU || o.type == IAK_OP_KMEANS ||
            (o.type == IAK_OP_GAUSS && (o.mean == -1 || o.stddev == -1));
 }
 bool hist_survives(int t) {  // histogram after the stage follows from the one before it
-    return t == IAK_OP_EQUALIZE || t == IAK_OP_THRESHOLD || t == IAK_OP_OTSU || t == IAK_OP_QUANTIZE;
+    return t == IAK_OP_EQUALIZE || t == IAK_OP_THRESHOLD || t == IAK_OP_OTSU || t == IAK_OP_QUANTIZE ||
+           t == IAK_OP_KMEANS;
 }
 const char *op_name(int t) {
     static const char *n[] = {"?", "equalize", "gauss", "salt_pepper", "linear", "average", "median", "sobel",
-                              "compass", "dilate", "erode", "threshold", "otsu", "quantize"};
-    return (t >= 1 && t <= 13) ? n[t] : "?";
+                              "compass", "dilate", "erode", "threshold", "otsu", "quantize", "kmeans", "features"};
+    return (t >= 1 && t <= 15) ? n[t] : "?";
 }
 // stage-wise compulsory traffic per pixel: every stage reads its input and writes its output;
 // the noise stages also read one plane byte
 long long op_alg_bytes(int t) {
     if (t == IAK_OP_GAUSS || t == IAK_OP_SALT_PEPPER) return 3;
+    if (t == IAK_OP_FEATURES) return 1;  // as built here: one read of the image (plus a histogram pass when needed)
     return 2;
 }
 
@@ -403,6 +306,17 @@ struct iak_pipeline {
     uint16_t *tables = nullptr; // [maxB][CHAIN_MAX][256]
     uint32_t *x0 = nullptr, *x1 = nullptr;
     uint8_t *rv = nullptr;
+    // k-means: the libc rand() state the centroid draws continue from run to run, and the draws
+    // of the current run, [n_kmeans][B][2]
+    int n_kmeans = 0;
+    uint32_t *rand_state = nullptr;
+    int32_t *kmeans_init = nullptr;
+    int run_B = 0;
+    // feature extraction: workspace ([maxB] slices of feat_ws_per_image bytes) and the bound output
+    int n_features = 0;
+    uint8_t *feat_ws = nullptr;
+    long long feat_ws_per_image = 0;
+    float *features_out = nullptr;
     std::vector<std::pair<int, uint8_t *>> sp;  // level -> plane
     // concurrency: the batch is cut into `lanes` sub-batches that run on their own streams, so
     // that bandwidth-bound and issue-bound kernels of different sub-batches overlap
@@ -427,7 +341,8 @@ struct iak_pipeline {
 };
 
 static void free_all(iak_pipeline *p) {
-    void *ptrs[] = {p->bufA, p->bufB, p->hist, p->hist2, p->map, p->thr, p->tables, p->x0, p->x1, p->rv};
+    void *ptrs[] = {p->bufA, p->bufB, p->hist, p->hist2, p->map, p->thr, p->tables, p->x0, p->x1, p->rv,
+                    p->rand_state, p->kmeans_init, p->feat_ws};
     for (void *q : ptrs) (void)hipFree(q);
     for (auto &e : p->sp) (void)hipFree(e.second);
     for (auto e : p->ev) (void)hipEventDestroy(e);
@@ -467,6 +382,10 @@ static int plan(iak_pipeline *p) {
                 switch (q.type) {
                 case IAK_OP_EQUALIZE: st.type = C_EQUALIZE; break;
                 case IAK_OP_OTSU: st.type = C_OTSU; break;
+                case IAK_OP_KMEANS:
+                    st.type = C_KMEANS;
+                    st.lut_slot = p->ops[i].kmeans_index;  // which k-means operation of the pipeline
+                    break;
                 case IAK_OP_THRESHOLD:
                     st.type = C_CONST_LUT;
                     st.lut_slot = luts;
@@ -526,10 +445,15 @@ static int plan(iak_pipeline *p) {
             continue;
         }
         Group g;
-        g.kind = G_OP;
+        g.kind = o.type == IAK_OP_FEATURES ? G_FEATURES : G_OP;
         g.op_index = i;
         g.name = op_name(o.type);
         g.alg_bytes = op_alg_bytes(o.type) + (needs_hist(o) ? 1 : 0);
+        if (g.kind == G_FEATURES) {  // the image and what is known about its histogram stay as they are
+            p->groups.push_back(g);
+            i++;
+            continue;
+        }
         p->groups.push_back(g);
         hist_known = false;
         i++;
@@ -571,6 +495,8 @@ int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op
             break;
         case IAK_OP_GAUSS: case IAK_OP_SALT_PEPPER: any_noise = true; break;
         case IAK_OP_EQUALIZE: case IAK_OP_SOBEL: case IAK_OP_COMPASS: case IAK_OP_THRESHOLD: case IAK_OP_OTSU: break;
+        case IAK_OP_KMEANS: c.kmeans_index = p->n_kmeans++; break;
+        case IAK_OP_FEATURES: p->n_features++; break;
         default: delete p; return IAK_E_ARG;
         }
         p->ops.push_back(std::move(c));
@@ -596,6 +522,16 @@ int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op
     TRY(hipMalloc((void **)&p->map, sizeof(int32_t) * 256 * (size_t)maxB));
     TRY(hipMalloc((void **)&p->thr, sizeof(int32_t) * (size_t)maxB));
     TRY(hipMalloc((void **)&p->tables, sizeof(uint16_t) * 256 * CHAIN_MAX * (size_t)maxB));
+    if (p->n_kmeans) {
+        TRY(hipMalloc((void **)&p->rand_state, sizeof(uint32_t) * IAK_GLIBC_RAND_WORDS));
+        TRY(hipMalloc((void **)&p->kmeans_init, sizeof(int32_t) * 2 * (size_t)p->n_kmeans * (size_t)maxB));
+        int rc = iak_glibc_rand_seed(p->rand_state, 1u, nullptr);  // a program that never calls srand
+        if (rc != 0) { free_all(p); delete p; return rc; }
+    }
+    if (p->n_features) {
+        p->feat_ws_per_image = iak_features_workspace_bytes(W, H, 1);
+        TRY(hipMalloc((void **)&p->feat_ws, (size_t)p->feat_ws_per_image * (size_t)maxB));
+    }
     if (any_noise) {
         // setupRandomness (imageAnalysis.cu:740-746): once per pipeline, outside the runs
         TRY(hipMalloc((void **)&p->x0, sizeof(uint32_t) * (size_t)p->N));
@@ -690,7 +626,7 @@ static Slice slice_of(const iak_pipeline *p, int b0) {
 }
 
 static int run_single_op(iak_pipeline *p, const Slice &sl, const iak_op &o, const uint8_t *src, uint8_t *dst, int B,
-                         void *stream) {
+                         const int32_t *kmeans_init, void *stream) {
     const int W = p->W, H = p->H;
     const long long N = p->N;
     switch (o.type) {
@@ -729,8 +665,27 @@ static int run_single_op(iak_pipeline *p, const Slice &sl, const iak_op &o, cons
         return iak_threshold_per_image(src, dst, N, B, N, N, sl.thr, stream);
     }
     case IAK_OP_QUANTIZE: return iak_quantize(src, dst, N, B, N, N, o.ikernel, o.iparam, stream);
+    case IAK_OP_KMEANS: {
+        int rc = iak_hist(src, sl.hist2, N, B, N, stream);
+        if (rc) return rc;
+        rc = iak_kmeans2_map(sl.hist2, (int)N, B, kmeans_init, sl.map, nullptr, stream);
+        if (rc) return rc;
+        return iak_apply_map(src, dst, N, B, N, N, sl.map, 256, stream);
+    }
     }
     return IAK_E_ARG;
+}
+
+// initial centroids of k-means operation k for the sub-batch that starts at image b0
+static const int32_t *kmeans_of(const iak_pipeline *p, int k, int b0) {
+    return k < 0 ? nullptr : p->kmeans_init + 2 * ((size_t)k * (size_t)p->run_B + (size_t)b0);
+}
+// the chain as the kernels of this sub-batch see it: k-means stages get their centroid slice
+static ChainDesc chain_for(const iak_pipeline *p, const ChainDesc &c, int b0) {
+    ChainDesc d = c;
+    for (int k = 0; k < d.n; k++)
+        if (d.st[k].type == C_KMEANS) d.st[k].plane = reinterpret_cast<const uint8_t *>(kmeans_of(p, d.st[k].lut_slot, b0));
+    return d;
 }
 
 static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, int B, unsigned long long *hist_sum,
@@ -743,7 +698,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
     // image-producing groups alternate between the two buffers; the last one writes `out`
     int producers = 0;
     for (auto &g : p->groups)
-        if (g.kind != G_HIST) producers++;
+        if (g.kind != G_HIST && g.kind != G_FEATURES) producers++;
     int produced = 0;
     const uint8_t *cur = nullptr;
     const uint32_t *cur_hist = nullptr;
@@ -752,7 +707,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
     for (int gi = 0; gi < ng; gi++) {
         const Group &g = p->groups[gi];
         uint8_t *dst = nullptr;
-        if (g.kind != G_HIST) {
+        if (g.kind != G_HIST && g.kind != G_FEATURES) {
             produced++;
             dst = (produced == producers) ? out : ((produced & 1) ? sl.bufA : sl.bufB);
         }
@@ -774,12 +729,13 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             cur_hist = sl.hist2;
             break;
         case G_CHAIN: {
+            const ChainDesc cd = chain_for(p, g.chain, b0);
             bool wants = false;
             for (int k = 0; k < g.chain.n; k++)
-                wants = wants || g.chain.st[k].type == C_EQUALIZE || g.chain.st[k].type == C_OTSU ||
+                wants = wants || g.chain.st[k].type == C_EQUALIZE || g.chain.st[k].type == C_OTSU || g.chain.st[k].type == C_KMEANS ||
                         (g.chain.st[k].type == C_GAUSS && (g.chain.st[k].mean == -1 || g.chain.st[k].stddev == -1));
             if (wants && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
-            hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, g.chain, sl.tables);
+            hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables);
             IAK_LAUNCH_CHECK();
             if (ev) {
                 p->split[gi] = 1;
@@ -787,26 +743,28 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             }
             bool vec = aligned16(cur) && aligned16(dst) && N % 16 == 0;
             for (int k = 0; k < g.chain.n; k++)
-                if (g.chain.st[k].plane) vec = vec && aligned16(g.chain.st[k].plane);
+                if (g.chain.st[k].plane && g.chain.st[k].type != C_KMEANS) vec = vec && aligned16(g.chain.st[k].plane);
             dim3 grid(blocks_x(vec ? N / 32 : N, 256, B, 32768), B);
             if (vec)
-                hipLaunchKernelGGL((chain_apply_kernel<true>), grid, dim3(256), 0, s, cur, dst, N, N, N, g.chain, sl.tables);
+                hipLaunchKernelGGL((chain_apply_kernel<true>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd, sl.tables);
             else
-                hipLaunchKernelGGL((chain_apply_kernel<false>), grid, dim3(256), 0, s, cur, dst, N, N, N, g.chain, sl.tables);
+                hipLaunchKernelGGL((chain_apply_kernel<false>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd, sl.tables);
             IAK_LAUNCH_CHECK();
             cur_hist = nullptr;
             break;
         }
         case G_CHAIN_OP: {
+            const ChainDesc cd = chain_for(p, g.chain, b0);
             bool wants = false;
             for (int k = 0; k < g.chain.n; k++)
-                wants = wants || g.chain.st[k].type == C_EQUALIZE || g.chain.st[k].type == C_OTSU ||
+                wants = wants || g.chain.st[k].type == C_EQUALIZE || g.chain.st[k].type == C_OTSU || g.chain.st[k].type == C_KMEANS ||
                         (g.chain.st[k].type == C_GAUSS && (g.chain.st[k].mean == -1 || g.chain.st[k].stddev == -1));
             if (wants && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
             if (!aligned16(cur) || (reinterpret_cast<uintptr_t>(dst) & 7u)) return IAK_E_UNSUPPORTED;
             for (int k = 0; k < g.chain.n; k++)
-                if (g.chain.st[k].plane && !aligned16(g.chain.st[k].plane)) return IAK_E_UNSUPPORTED;
-            hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, g.chain, sl.tables);
+                if (g.chain.st[k].plane && g.chain.st[k].type != C_KMEANS && !aligned16(g.chain.st[k].plane))
+                    return IAK_E_UNSUPPORTED;
+            hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables);
             IAK_LAUNCH_CHECK();
             if (ev) {
                 p->split[gi] = 1;
@@ -814,7 +772,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             }
             const iak_op &o = p->ops[g.op_index].op;
             auto go = [&](const auto &op) {
-                return launch_chain_stencil(cur, dst, p->W, p->H, B, g.chain, sl.tables, op, s);
+                return launch_chain_stencil(cur, dst, p->W, p->H, B, N, N, cd, sl.tables, op, s);
             };
             switch (o.type) {
             case IAK_OP_LINEAR: rc = with_linear3_op<false>(o.fkernel, go); break;
@@ -829,8 +787,14 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             cur_hist = nullptr;
             break;
         }
+        case G_FEATURES:
+            if (!p->features_out) return IAK_E_ARG;
+            rc = iak_features(cur, p->W, p->H, B, N, cur_hist, p->features_out + (size_t)b0 * IAK_N_FEATURES,
+                              p->feat_ws + (size_t)b0 * (size_t)p->feat_ws_per_image, s);
+            break;
         case G_OP:
-            rc = run_single_op(p, sl, p->ops[g.op_index].op, cur, dst, B, s);
+            rc = run_single_op(p, sl, p->ops[g.op_index].op, cur, dst, B,
+                               kmeans_of(p, p->ops[g.op_index].kmeans_index, b0), s);
             cur_hist = nullptr;
             break;
         }
@@ -857,6 +821,12 @@ int iak_pipeline_set_lanes(iak_pipeline *p, int lanes) {
     return 0;
 }
 
+int iak_pipeline_bind_features(iak_pipeline *p, float *features) {
+    if (!p) return IAK_E_ARG;
+    p->features_out = features;
+    return 0;
+}
+
 int iak_pipeline_timed_images(iak_pipeline *p) { return p ? p->timed_images : IAK_E_ARG; }
 
 int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, unsigned long long *hist_sum,
@@ -866,6 +836,11 @@ int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, u
     const int ng = (int)p->groups.size();
     const hipEvent_t *ev = p->slots ? p->ev.data() + (size_t)(p->runs_timed % p->slots) * (2 * ng + 1) : nullptr;
     const int lanes = (p->lanes > B) ? B : p->lanes;
+    p->run_B = B;
+    if (p->n_kmeans) {  // this run's rand() draws, two per image per k-means operation, in image order
+        int rc = iak_glibc_rand_centroids(p->rand_state, B, p->n_kmeans, p->kmeans_init, stream);
+        if (rc) return rc;
+    }
     if (lanes <= 1) {
         int rc = run_range(p, rgb, out, 0, B, hist_sum, gray_hist, s, ev);
         if (rc) return rc;

@@ -11,7 +11,10 @@ IAK_E_ARG, IAK_E_UNSUPPORTED, IAK_E_TOO_LARGE = -1, -2, -3
 IAK_LINEAR_CLAMP, IAK_LINEAR_AVERAGE = 0, 1
 IAK_PIPE_STAGEWISE, IAK_PIPE_FUSED, IAK_PIPE_FUSED_POINTWISE = 0, 1, 2
 (IAK_OP_EQUALIZE, IAK_OP_GAUSS, IAK_OP_SALT_PEPPER, IAK_OP_LINEAR, IAK_OP_AVERAGE, IAK_OP_MEDIAN, IAK_OP_SOBEL,
- IAK_OP_COMPASS, IAK_OP_DILATE, IAK_OP_ERODE, IAK_OP_THRESHOLD, IAK_OP_OTSU, IAK_OP_QUANTIZE) = range(1, 14)
+ IAK_OP_COMPASS, IAK_OP_DILATE, IAK_OP_ERODE, IAK_OP_THRESHOLD, IAK_OP_OTSU, IAK_OP_QUANTIZE, IAK_OP_KMEANS,
+ IAK_OP_FEATURES) = range(1, 16)
+IAK_N_FEATURES = 7
+IAK_GLIBC_RAND_WORDS = 35
 
 
 class IakOp(C.Structure):
@@ -56,6 +59,12 @@ SIGNATURES = {
     "iak_compass": [_vp, _vp, _i, _i, _i, _ll, _ll, _vp],
     "iak_dilate": [_vp, _vp, _i, _i, _i, _ll, _ll, _vp, _i, _i, _vp],
     "iak_erode": [_vp, _vp, _i, _i, _i, _ll, _ll, _vp, _i, _i, _vp],
+    "iak_features_workspace_bytes": [_i, _i, _i],
+    "iak_features": [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp],
+    "iak_kmeans2_map": [_vp, _i, _i, _vp, _vp, _vp, _vp],
+    "iak_glibc_rand_seed": [_vp, C.c_uint, _vp],
+    "iak_glibc_rand_centroids": [_vp, _i, _i, _vp, _vp],
+    "iak_pipeline_bind_features": [_vp, _vp],
     "iak_pipeline_create": [C.POINTER(_vp), _i, _i, _i, _vp, _i, C.c_ulonglong, _i],
     "iak_pipeline_destroy": [_vp],
     "iak_pipeline_run": [_vp, _vp, _vp, _i, _vp, _vp, _vp],
@@ -64,7 +73,7 @@ SIGNATURES = {
     "iak_pipeline_set_timing": [_vp, _i],
     "iak_pipeline_timings": [_vp, _i, _vp, _vp, _vp, _vp, _i],
 }
-_RESTYPE = {"iak_error_string": C.c_char_p}
+_RESTYPE = {"iak_error_string": C.c_char_p, "iak_features_workspace_bytes": C.c_longlong}
 
 _lib = None
 

@@ -242,3 +242,57 @@ def imageDilation(img, se, kW, kH):
 def imageErosion(img, se, kW, kH):
     k = np.ascontiguousarray(np.asarray(se, np.int32).reshape(-1))
     return _stencil("iak_erode", img, k, kW, kH)
+
+
+class LibcRand:
+    """The libc rand() stream the reference's k-means draws its centroids from
+    (imageAnalysis.cu:39-41,359-361), reproduced on the device: state after srand(seed);
+    a program that never calls srand behaves as srand(1)."""
+
+    def __init__(self, seed=1, device=None):
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.state = torch.zeros(_l.IAK_GLIBC_RAND_WORDS, dtype=torch.int32, device=dev)
+        _l.check(_l.load().iak_glibc_rand_seed(self.state.data_ptr(), int(seed), _stream()), "iak_glibc_rand_seed")
+
+    def centroids(self, images, ops_per_image=1):
+        """The next images*ops_per_image pairs of random(0,256), as int32 [ops_per_image, images, 2]."""
+        out = torch.empty((ops_per_image, images, 2), dtype=torch.int32, device=self.state.device)
+        _l.check(_l.load().iak_glibc_rand_centroids(self.state.data_ptr(), images, ops_per_image, out.data_ptr(),
+                                                    _stream()), "iak_glibc_rand_centroids")
+        return out
+
+
+def kMeansThresholding(img, init_centroids, return_iterations=False):
+    """imageAnalysis.cu:351-379 for a batch: init_centroids int32 [B, 2] (CUDA), e.g.
+    LibcRand().centroids(B)[0]."""
+    x = _b3(img)
+    B, H, W = x.shape
+    hist = calculateHistogram(x)
+    ini = init_centroids.contiguous().view(-1, 2)
+    assert ini.shape[0] == B and ini.dtype == torch.int32 and ini.is_cuda
+    m = torch.empty((B, 256), dtype=torch.int32, device=x.device)
+    it = torch.empty((B,), dtype=torch.int32, device=x.device)
+    _l.check(_l.load().iak_kmeans2_map(hist.data_ptr(), H * W, B, ini.data_ptr(), m.data_ptr(), it.data_ptr(), _stream()),
+             "iak_kmeans2_map")
+    out = equalizeImageWithHist(x, m)
+    out = _ret(out, img)
+    return (out, it) if return_iterations else out
+
+
+def featureExtraction(img, hist=None):
+    """imageMachineLearning.cu:393-415 for a batch: float32 [B, 7] = mean, std, area, perimeter,
+    mode, rangeMin, rangeMax."""
+    x = _b3(img)
+    B, H, W = x.shape
+    L = _l.load()
+    nbytes = L.iak_features_workspace_bytes(W, H, B)
+    if nbytes < 0:
+        raise _l.IakError(int(nbytes), "iak_features_workspace_bytes")
+    ws = torch.empty((nbytes + 256,), dtype=torch.uint8, device=x.device)
+    base = (ws.data_ptr() + 255) & ~255
+    feats = torch.empty((B, _l.IAK_N_FEATURES), dtype=torch.float32, device=x.device)
+    h = hist.contiguous() if hist is not None else None
+    _l.check(L.iak_features(x.data_ptr(), W, H, B, _istride(x), h.data_ptr() if h is not None else None, feats.data_ptr(),
+                            base, _stream()), "iak_features")
+    torch.cuda.current_stream().synchronize()  # ws is freed on return
+    return feats if img.dim() == 3 else feats[0]

@@ -13,6 +13,7 @@ _NAMES = {
     "average-filter": _l.IAK_OP_AVERAGE, "median-filter": _l.IAK_OP_MEDIAN, "sobel-filter": _l.IAK_OP_SOBEL,
     "compass-filter": _l.IAK_OP_COMPASS, "dilation": _l.IAK_OP_DILATE, "erosion": _l.IAK_OP_ERODE,
     "threshold": _l.IAK_OP_THRESHOLD, "otsu-thresh": _l.IAK_OP_OTSU, "quantization": _l.IAK_OP_QUANTIZE,
+    "kMeans-thresh": _l.IAK_OP_KMEANS, "feature-extract": _l.IAK_OP_FEATURES,
 }
 
 
@@ -112,6 +113,13 @@ class Pipeline:
             gray_hist.data_ptr() if gray_hist is not None else None, torch.cuda.current_stream().cuda_stream),
             "iak_pipeline_run")
         return out
+
+    def bind_features(self, features):
+        """features: float32 [maxB, 7] CUDA tensor the feature-extract operation writes."""
+        assert features.is_cuda and features.dtype == torch.float32 and features.is_contiguous()
+        assert features.shape == (self.maxB, _l.IAK_N_FEATURES)
+        self._features = features  # keep it alive
+        _l.check(_l.load().iak_pipeline_bind_features(self._h, features.data_ptr()), "iak_pipeline_bind_features")
 
     def set_lanes(self, lanes):
         """Run every batch as `lanes` concurrent sub-batches (see iak_pipeline_set_lanes)."""

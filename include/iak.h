@@ -159,6 +159,34 @@ int iak_erode(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in
               long long out_stride, const int *se, int kW, int kH, void *stream);
 
 
+/* ---- features and k-means thresholding for batches ------------------------------------------- */
+#define IAK_N_FEATURES 7
+/* featureExtraction (imageMachineLearning.cu:393-415) for B images: features[b] = {mean, stddev
+ * (calculateMeanAndStdDev, imageAnalysis.cu:106-128), area = min(#mask, N - #mask) of the Otsu
+ * mask (:353-360), perimeter = number of 255s in the compass filter of that mask (:362-366),
+ * mode (:341-351), rangeMin, rangeMax (:379-390; -1 for an all-zero image)}.  DEVICE float[B][7].
+ * hist: the images' histograms [B][256] (bin 0 empty) if the caller has them, else NULL.
+ * workspace: DEVICE memory of iak_features_workspace_bytes(W, H, B) bytes, 256-byte aligned.
+ * W % 16 == 0 with 16-byte aligned images reads each image once and stores no image. */
+long long iak_features_workspace_bytes(int W, int H, int B);
+int iak_features(const uint8_t *img, int W, int H, int B, long long stride, const uint32_t *hist,
+                 float *features, void *workspace, void *stream);
+/* kMeansThresholding (imageAnalysis.cu:281-379; k = 2) on histograms: map[b][v] = 0 or 255, the
+ * value applyLabels (:339-349) gives a pixel of value v; apply it with iak_apply_map.
+ * init_centroids: DEVICE int32[B][2], the two random(0,256) draws of each image (:359-361).
+ * iterations: DEVICE int32[B] or NULL. */
+int iak_kmeans2_map(const uint32_t *hist, int numPixels, int B, const int32_t *init_centroids,
+                    int32_t *map, int32_t *iterations, void *stream);
+/* The reference draws those centroids from libc rand() and never seeds it, so they are a fixed
+ * sequence.  state: DEVICE uint32[35].  _seed writes the state srand(seed) leaves (1 = the
+ * unseeded program) and synchronises; _centroids draws the next images * ops_per_image * 2
+ * values of random(0,256) = rand() / (RAND_MAX / 257 + 1) in the reference's order (image by
+ * image, within an image one pair per k-means operation), stores them operation-major,
+ * out[(op * images + image) * 2 + j] (DEVICE int32), and advances the state. */
+#define IAK_GLIBC_RAND_WORDS 35
+int iak_glibc_rand_seed(uint32_t *state, unsigned seed, void *stream);
+int iak_glibc_rand_centroids(uint32_t *state, int images, int ops_per_image, int32_t *out, void *stream);
+
 /* ---- batched pipeline executor ------------------------------------------------------------
  * Replaces the per-image / per-operation loop of executeOperations (test/test.cu:266-564)
  * for a whole batch that is resident on the device: grayscale (luminance) + histogram,
@@ -178,7 +206,11 @@ enum {
     IAK_OP_ERODE = 10,      /* test.cu:485-499 */
     IAK_OP_THRESHOLD = 11,  /* test.cu:500-509  iparam = threshold */
     IAK_OP_OTSU = 12,       /* test.cu:510-518 */
-    IAK_OP_QUANTIZE = 13    /* test.cu:420-443  ikernel = levels {min,max,val}, iparam = numLevels */
+    IAK_OP_QUANTIZE = 13,   /* test.cu:420-443  ikernel = levels {min,max,val}, iparam = numLevels */
+    IAK_OP_KMEANS = 14,     /* test.cu:519-532  kMeans-thresh (k = 2; centroids from the unseeded rand() sequence,
+                             * two draws per image in image order, continuing from run to run) */
+    IAK_OP_FEATURES = 15    /* test.cu:533-555  feature-extract: leaves the image as it is and writes the 7 features
+                             * of every image to the array bound with iak_pipeline_bind_features */
 };
 typedef struct {
     int type;
@@ -212,6 +244,9 @@ int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B,
  * and issue-bound kernels of different sub-batches overlap.  Results are unchanged.  This call
  * may create streams and events; runs do not.  Default 1. */
 int iak_pipeline_set_lanes(iak_pipeline *p, int lanes);
+/* Where IAK_OP_FEATURES writes: DEVICE float[maxB][7], image b of a run at features + 7 * b.
+ * Required before running a pipeline that has that operation. */
+int iak_pipeline_bind_features(iak_pipeline *p, float *features);
 /* Number of images the timed sub-batch of the most recent run held (all of them with 1 lane). */
 int iak_pipeline_timed_images(iak_pipeline *p);
 /* Per-launch-group timing.  set_timing(p, slots) (re)creates `slots` sets of HIP events

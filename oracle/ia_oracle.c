@@ -634,14 +634,24 @@ void iao_features(const uint8_t *in, int W, int H, float *feat) {
 /* ------------------------------------------------------------- pipelines */
 
 static void run_ops_one(const uint8_t *rgb, uint8_t *out, int W, int H, const iao_op *ops, int nops,
-                        const uint32_t *x0, const uint32_t *x1, int *hist, uint8_t *tmp) {
+                        const uint32_t *x0, const uint32_t *x1, int *hist, uint8_t *tmp, const int *centroids,
+                        float *features) {
     long N = (long)W * H;
     uint8_t *cur = out, *nxt = tmp;
+    int kmeans_seen = 0;
     iao_gray(rgb, cur, W, H, 0);
     iao_hist(cur, N, hist);
     for (int i = 0; i < nops; i++) {
         const iao_op *op = &ops[i];
+        if (op->type == IAO_OP_FEATURES) { /* test.cu:533-555: the image stays as it is */
+            if (features) iao_features(cur, W, H, features);
+            continue;
+        }
         switch (op->type) {
+        case IAO_OP_KMEANS: /* test.cu:519-532; the two random(0,256) draws of this call */
+            iao_kmeans2(cur, nxt, N, centroids[2 * kmeans_seen], centroids[2 * kmeans_seen + 1]);
+            kmeans_seen++;
+            break;
         case IAO_OP_EQUALIZE: { /* test.cu:404-419 */
             int h[256], map[256];
             iao_hist(cur, N, h);
@@ -672,7 +682,15 @@ static void run_ops_one(const uint8_t *rgb, uint8_t *out, int W, int H, const ia
 
 void iao_pipeline(const uint8_t *rgb, uint8_t *out, int W, int H, int B, const iao_op *ops, int nops,
                   const uint32_t *x0, const uint32_t *x1, long long *hist_sum, int threads) {
+    iao_pipeline_ex(rgb, out, W, H, B, ops, nops, x0, x1, hist_sum, threads, NULL, NULL);
+}
+
+void iao_pipeline_ex(const uint8_t *rgb, uint8_t *out, int W, int H, int B, const iao_op *ops, int nops,
+                     const uint32_t *x0, const uint32_t *x1, long long *hist_sum, int threads, const int *centroids,
+                     float *features) {
     long N = (long)W * H;
+    int nk = 0;
+    for (int i = 0; i < nops; i++) nk += ops[i].type == IAO_OP_KMEANS;
     if (hist_sum) memset(hist_sum, 0, 256 * sizeof(long long));
     if (threads < 1) threads = 1;
 #pragma omp parallel num_threads(threads)
@@ -683,7 +701,8 @@ void iao_pipeline(const uint8_t *rgb, uint8_t *out, int W, int H, int B, const i
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < B; b++) {
             int hist[256];
-            run_ops_one(rgb + (size_t)b * 3 * N, out + (size_t)b * N, W, H, ops, nops, x0, x1, hist, tmp);
+            run_ops_one(rgb + (size_t)b * 3 * N, out + (size_t)b * N, W, H, ops, nops, x0, x1, hist, tmp,
+                        centroids ? centroids + (size_t)b * 2 * nk : NULL, features ? features + (size_t)b * 7 : NULL);
             for (int v = 0; v < 256; v++) local[v] += hist[v];
         }
         if (hist_sum) {

@@ -117,7 +117,7 @@ enum {
     IAO_OP_EQUALIZE = 1, IAO_OP_GAUSS = 2, IAO_OP_SALT_PEPPER = 3, IAO_OP_LINEAR = 4,
     IAO_OP_AVERAGE = 5, IAO_OP_MEDIAN = 6, IAO_OP_SOBEL = 7, IAO_OP_COMPASS = 8,
     IAO_OP_DILATE = 9, IAO_OP_ERODE = 10, IAO_OP_THRESHOLD = 11, IAO_OP_OTSU = 12,
-    IAO_OP_QUANTIZE = 13
+    IAO_OP_QUANTIZE = 13, IAO_OP_KMEANS = 14, IAO_OP_FEATURES = 15
 };
 typedef struct {
     int type;
@@ -133,6 +133,15 @@ typedef struct {
 void iao_pipeline(const uint8_t *rgb, uint8_t *out, int W, int H, int B,
                   const iao_op *ops, int nops, const uint32_t *x0, const uint32_t *x1,
                   long long *hist_sum, int threads);
+/* As iao_pipeline, with the two operations that need more than the image:
+ * IAO_OP_KMEANS (test/test.cu:519-532) takes its two initial centroids from
+ * centroids[(b * nk + k) * 2 + {0,1}], the random(0,256) draws (imageAnalysis.cu:39-41,
+ * 359-361) of image b's k-th k-means operation, nk = number of such operations;
+ * IAO_OP_FEATURES (test/test.cu:533-555) leaves the image alone and writes
+ * features[b * 7 ..] (imageMachineLearning.cu:393-415). */
+void iao_pipeline_ex(const uint8_t *rgb, uint8_t *out, int W, int H, int B,
+                     const iao_op *ops, int nops, const uint32_t *x0, const uint32_t *x1,
+                     long long *hist_sum, int threads, const int *centroids, float *features);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 
 OP_EQUALIZE, OP_GAUSS, OP_SALT_PEPPER, OP_LINEAR, OP_AVERAGE, OP_MEDIAN, OP_SOBEL, OP_COMPASS, \
-    OP_DILATE, OP_ERODE, OP_THRESHOLD, OP_OTSU, OP_QUANTIZE = range(1, 14)
+    OP_DILATE, OP_ERODE, OP_THRESHOLD, OP_OTSU, OP_QUANTIZE, OP_KMEANS, OP_FEATURES = range(1, 16)
 
 
 class IaoOp(C.Structure):
@@ -77,6 +77,7 @@ def lib():
     L.iao_features.argtypes = [u8p, C.c_int, C.c_int, f32p]
     L.iao_pipeline.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.POINTER(IaoOp), C.c_int,
                                C.c_void_p, C.c_void_p, i64p, C.c_int]
+    L.iao_pipeline_ex.argtypes = L.iao_pipeline.argtypes + [C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -286,6 +287,40 @@ def make_ops(ops):
         arr[i].mean = o.get("mean", -1.0)
         arr[i].stddev = o.get("stddev", -1.0)
     return arr, keep
+
+
+_libc = None
+
+
+def libc_random_0_256(n, skip=0):
+    """The first skip+n values of the reference's random(0, 256) (imageAnalysis.cu:39-41) in a
+    program that never calls srand, from the C library itself: srand(1), then
+    rand() / (RAND_MAX / 257 + 1).  Returns the last n."""
+    global _libc
+    if _libc is None:
+        _libc = C.CDLL("libc.so.6")
+        _libc.rand.restype = C.c_int
+    _libc.srand(1)
+    vals = [_libc.rand() // (2147483647 // 257 + 1) for _ in range(skip + n)]
+    return np.asarray(vals[skip:], np.int32)
+
+
+def pipeline_ex(rgb, ops, x0=None, x1=None, threads=1, centroids=None):
+    """As pipeline(); ops may hold OP_KMEANS (centroids: int32 [B, nk, 2], the rand() draws in
+    the reference's order) and OP_FEATURES.  Returns (out, hist, features [B, 7])."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    B, _, H, W = rgb.shape
+    out = np.empty((B, H, W), np.uint8)
+    hs = np.zeros(256, np.int64)
+    feats = np.zeros((B, 7), np.float32)
+    arr, keep = make_ops(ops)
+    cen = np.ascontiguousarray(centroids, np.int32) if centroids is not None else None
+    lib().iao_pipeline_ex(rgb.reshape(-1), out.reshape(-1), W, H, B, arr, len(ops),
+                          x0.ctypes.data if x0 is not None else None,
+                          x1.ctypes.data if x1 is not None else None, hs, threads,
+                          cen.ctypes.data if cen is not None else None, feats.ctypes.data)
+    del keep
+    return out, hs, feats
 
 
 def pipeline(rgb, ops, x0=None, x1=None, threads=1):
