@@ -37,6 +37,9 @@ struct Scratch {
     int32_t *thr = nullptr;     // 1
     float *ms = nullptr;        // 2
     uint32_t *sum = nullptr;    // 1
+    float *feat = nullptr;      // 7
+    void *feat_ws = nullptr;    // iak_features workspace, grown on demand
+    long long feat_ws_bytes = 0;
     void ensure() {
         if (hist) return;
         IAK_CHECK(iak_malloc((void **)&hist, 256 * sizeof(uint32_t)));
@@ -45,6 +48,7 @@ struct Scratch {
         IAK_CHECK(iak_malloc((void **)&thr, sizeof(int32_t)));
         IAK_CHECK(iak_malloc((void **)&ms, 2 * sizeof(float)));
         IAK_CHECK(iak_malloc((void **)&sum, sizeof(uint32_t)));
+        IAK_CHECK(iak_malloc((void **)&feat, IAK_N_FEATURES * sizeof(float)));
     }
 } g_scratch;
 
@@ -351,39 +355,31 @@ void imageErosion(Image *image, Image *output, int *structuringElement, int kWid
 
 // ---- feature extraction (imageMachineLearning.cu:341-422) -----------------------------------------------
 std::vector<float> featureExtraction(Image *image, Image *tempImage, int *h_histogram, int *d_histogram) {
-    std::vector<float> features;
-    float mean, stdDev;
-    calculateMeanAndStdDev(image, &mean, &stdDev);
-    Image tempImage2;
-    otsuThresholdImage(image, tempImage);
-    calculateHistogram(tempImage, h_histogram, d_histogram);
-    const int total = image->height * image->width;
-    const int area = std::min(h_histogram[255], total - h_histogram[255]);  // :353-360
-    compassFilter(tempImage, &tempImage2);
-    calculateHistogram(&tempImage2, h_histogram, d_histogram);
-    const int perimeter = h_histogram[255];  // :362-366
-    calculateHistogram(image, h_histogram, d_histogram);
-    int maxVal = 0, mode = -1;  // :341-351
-    for (int i = 0; i < 256; i++)
-        if (maxVal < h_histogram[i]) {
-            maxVal = h_histogram[i];
-            mode = i;
-        }
-    int rangeMin = -1, rangeMax = -1;  // :379-390
-    for (int i = 0; i < 256; ++i)
-        if (h_histogram[i] != 0 && rangeMin == -1) rangeMin = i;
-    for (int i = 255; i >= 0; i--)
-        if (h_histogram[i] != 0 && rangeMin != -1 && rangeMax == -1) rangeMax = i;
-    features.push_back(mean);
-    features.push_back(stdDev);
-    features.push_back((float)area);
-    features.push_back((float)perimeter);
-    features.push_back((float)mode);
-    features.push_back((float)rangeMin);
-    features.push_back((float)rangeMax);
-    IAK_CHECK(iak_free(tempImage2.image));
-    IAK_CHECK(iak_free(tempImage->image));
-    return features;
+    // imageMachineLearning.cu:393-415.  The reference makes six image passes (statistics, Otsu
+    // mask, its histogram, compass filter, its histogram, the image's histogram); here the
+    // histogram is taken once and iak_features derives everything from it plus one more read
+    // of the image.  Observable leftovers are kept: h_histogram ends up holding the image's
+    // histogram, tempImage carries the image's size and no buffer (the reference frees it).
+    (void)d_histogram;
+    g_scratch.ensure();
+    const long long n = pixels(image);
+    const long long need = iak_features_workspace_bytes(image->width, image->height, 1);
+    if (need < 0) IAK_CHECK((int)need);
+    if (g_scratch.feat_ws_bytes < need) {
+        if (g_scratch.feat_ws) IAK_CHECK(iak_free(g_scratch.feat_ws));
+        IAK_CHECK(iak_malloc(&g_scratch.feat_ws, (size_t)need));
+        g_scratch.feat_ws_bytes = need;
+    }
+    IAK_CHECK(iak_hist(image->image, g_scratch.hist, n, 1, n, nullptr));
+    IAK_CHECK(iak_features(image->image, image->width, image->height, 1, n, g_scratch.hist, g_scratch.feat,
+                           g_scratch.feat_ws, nullptr));
+    float f[IAK_N_FEATURES];
+    IAK_CHECK(iak_memcpy_d2h(f, g_scratch.feat, sizeof f, nullptr));
+    IAK_CHECK(iak_memcpy_d2h(h_histogram, g_scratch.hist, 256 * sizeof(int), nullptr));
+    tempImage->width = image->width;
+    tempImage->height = image->height;
+    tempImage->image = nullptr;
+    return std::vector<float>(f, f + IAK_N_FEATURES);
 }
 
 std::vector<float> extractAllPixelsAsFeatures(Image *image) {
