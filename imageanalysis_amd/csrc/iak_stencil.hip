@@ -12,23 +12,9 @@
 //   * a generic path (any width, any kW x kH up to IAK_MAX_TAPS), one pixel per lane.
 #include "iak_common.hpp"
 #include "iak_stencil_ops.hpp"
+#include "iak_stencil_tiled.hpp"
 
 namespace iak {
-
-struct Taps {  // by-value kernel argument
-    float f[IAK_MAX_TAPS];
-};
-struct ITaps {
-    int v[IAK_MAX_TAPS];
-};
-
-__device__ __forceinline__ bool is_border(int row, int col, int W, int H, int a, int s) {
-    return row < a || row > (H - a) || col < s || col > (W - s);
-}
-
-__device__ __forceinline__ uint32_t tap_at(const uint8_t *img, long long N, long long idx) {
-    return (idx >= 0 && idx < N) ? img[idx] : 0u;
-}
 
 // =======================================================================================
 // Generic path
@@ -314,6 +300,9 @@ int iak_linear(const uint8_t *in, uint8_t *out, int W, int H, int B, long long i
     const int a = (kH - 1) / 2, s = (kW - 1) / 2;
     const int visited = (2 * a + 1) * (2 * s + 1);
     for (int i = 0; i < visited; i++) t.f[i] = kernel[i];
+    rc = launch_tiled_linear(in, out, W, H, B, in_stride, out_stride, 2 * s + 1, 2 * a + 1, kW * kH,
+                             mode == IAK_LINEAR_AVERAGE, t, as_stream(stream));
+    if (rc != IAK_E_UNSUPPORTED) return rc;
     if (mode == IAK_LINEAR_CLAMP)
         hipLaunchKernelGGL((generic_float_kernel<G_LINEAR>), generic_grid(W, H, B), dim3(256), 0, as_stream(stream), in,
                            out, W, H, in_stride, out_stride, kW, kH, t);
@@ -341,6 +330,10 @@ int iak_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long i
     if (kernSum <= 0 || kernSum > 0x7fffffff) return IAK_E_UNSUPPORTED;
     if (kW == 3 && kH == 3 && ones && fast8_ok(in, out, W, H, in_stride, out_stride))
         return launch8(in, out, W, H, B, in_stride, out_stride, Median8(), stream);
+    if (ones) {
+        rc = launch_huang_median(in, out, W, H, B, in_stride, out_stride, kW, kH, as_stream(stream));
+        if (rc != IAK_E_UNSUPPORTED) return rc;
+    }
     ITaps t;
     for (int i = 0; i < kW * kH; i++) t.v[i] = weights[i];
     hipLaunchKernelGGL(generic_median_kernel, generic_grid(W, H, B), dim3(256), 0, as_stream(stream), in, out, W, H,

@@ -1,0 +1,275 @@
+// Neighbourhoods larger than 3x3: an LDS-tiled linear / average filter and a sliding-histogram
+// median.  Both work on the flat view of the image (a tap one past the right edge is the next
+// row's first pixel, taps outside [0, W*H) read 0), exactly like the one-pixel-per-lane
+// kernels they take over from.
+#pragma once
+#include "iak_common.hpp"
+
+namespace iak {
+
+struct Taps {  // by-value kernel argument
+    float f[IAK_MAX_TAPS];
+};
+struct ITaps {
+    int v[IAK_MAX_TAPS];
+};
+
+__device__ __forceinline__ bool is_border(int row, int col, int W, int H, int a, int s) {
+    return row < a || row > (H - a) || col < s || col > (W - s);
+}
+
+__device__ __forceinline__ uint32_t tap_at(const uint8_t *img, long long N, long long idx) {
+    return (idx >= 0 && idx < N) ? img[idx] : 0u;
+}
+
+// ---------------------------------------------------------------------------------------
+// Linear / average filter, KW x kH taps (KW odd, compile time; kH odd, run time).
+// A workgroup of 256 lanes produces a 64 x 32 tile of outputs from a (32+kH-1) x (64+KW-1)
+// tile of the image staged in LDS; a lane owns 8 adjacent outputs of one row and walks the
+// taps in the reference's order (rows outer, columns inner), adding each product to a running
+// sum that is truncated toward zero after every tap (imageAnalysis.cu:517-524: `int sum`
+// receives `sum + uchar * float`).  The sum is kept as a float holding an integer: with
+// sum(|k|) * 255 < 2^24 every intermediate is exact, so trunc(float) equals the reference's
+// float -> int -> float round trip.  Per tap and output: multiply, add, truncate.
+// ---------------------------------------------------------------------------------------
+#define TL_TW 64
+#define TL_TH 32
+template <int KW, bool AVG>
+__global__ __launch_bounds__(256) void tiled_linear_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
+                                                           int H, long long in_stride, long long out_stride, int kH,
+                                                           int divisor, int tiles_x, Taps taps) {
+    constexpr int PITCH = ((TL_TW + KW - 1 + 3) / 4) * 4 + ((((TL_TW + KW - 1 + 3) / 4) & 1) ? 0 : 4);  // odd number of dwords
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    const long long N = (long long)W * H;
+    const uint8_t *src = in + (long long)blockIdx.y * in_stride;
+    uint8_t *dst = out + (long long)blockIdx.y * out_stride;
+    const int a = (kH - 1) / 2, s = (KW - 1) / 2;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * TL_TW, y0 = ty * TL_TH;
+    const int rows = TL_TH + kH - 1, cols = TL_TW + KW - 1;
+    for (int e = threadIdx.x; e < rows * cols; e += 256) {
+        const int r = e / cols, c = e - r * cols;
+        const long long idx = (long long)(y0 - a + r) * W + (x0 - s + c);
+        tile[r * PITCH + c] = (uint8_t)tap_at(src, N, idx);
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 7, ly = threadIdx.x >> 3;
+    const int row = y0 + ly, col0 = x0 + lx * 8;
+    if (row >= H || col0 >= W) return;
+    float sum[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) sum[i] = 0.0f;
+    constexpr int NPX = 8 + KW - 1;
+    constexpr int NW = (NPX + 3) / 4;
+    for (int r = 0; r < kH; r++) {
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(tile + (ly + r) * PITCH + lx * 8);
+        float px[NW * 4];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint32_t v = rp[w];
+            px[4 * w + 0] = (float)(v & 0xffu);
+            px[4 * w + 1] = (float)((v >> 8) & 0xffu);
+            px[4 * w + 2] = (float)((v >> 16) & 0xffu);
+            px[4 * w + 3] = (float)(v >> 24);
+        }
+#pragma unroll
+        for (int j = 0; j < KW; j++) {
+            const float k = taps.f[r * KW + j];
+#pragma unroll
+            for (int i = 0; i < 8; i++) sum[i] = __builtin_truncf(sum[i] + px[i + j] * k);
+        }
+    }
+    uint32_t o[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int v = (int)sum[i];
+        uint32_t r8;
+        if (AVG) r8 = (uint32_t)(v / divisor) & 0xffu;  // imageAnalysis.cu:487: no clamp, wraps
+        else r8 = (uint32_t)(v > 255 ? 255 : (v < 0 ? 0 : v));
+        o[i] = is_border(row, col0 + i, W, H, a, s) ? 0u : r8;
+    }
+    uint8_t *q = dst + (long long)row * W + col0;
+    if (col0 + 8 <= W && ((reinterpret_cast<uintptr_t>(q) & 7u) == 0)) {
+        st8<true>(q, o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24), o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (col0 + i < W) q[i] = (uint8_t)o[i];
+    }
+}
+
+template <int KW>
+static size_t tiled_linear_lds(int kH) {
+    constexpr int PITCH = ((TL_TW + KW - 1 + 3) / 4) * 4 + ((((TL_TW + KW - 1 + 3) / 4) & 1) ? 0 : 4);
+    return (size_t)(TL_TH + kH - 1) * PITCH + 16;  // the last row's dword reads may run a few bytes past its pixels
+}
+
+template <int KW>
+static int launch_tiled_linear_kw(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+                                  long long out_stride, int kH, int divisor, bool avg, const Taps &t, hipStream_t s) {
+    const int tiles_x = (W + TL_TW - 1) / TL_TW, tiles_y = (H + TL_TH - 1) / TL_TH;
+    const dim3 grid((unsigned)(tiles_x * tiles_y), B);
+    const size_t lds = tiled_linear_lds<KW>(kH);
+    if (avg)
+        hipLaunchKernelGGL((tiled_linear_kernel<KW, true>), grid, dim3(256), lds, s, in, out, W, H, in_stride, out_stride, kH,
+                           divisor, tiles_x, t);
+    else
+        hipLaunchKernelGGL((tiled_linear_kernel<KW, false>), grid, dim3(256), lds, s, in, out, W, H, in_stride, out_stride, kH,
+                           divisor, tiles_x, t);
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
+// kWe, kHe: the odd window actually visited.  Returns IAK_E_UNSUPPORTED when this path does not
+// apply (the caller then uses the one-pixel-per-lane kernel).
+static int launch_tiled_linear(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+                               long long out_stride, int kWe, int kHe, int divisor, bool avg, const Taps &t, hipStream_t s) {
+    if (kWe > 25 || kHe > 25 || (long long)W * H >= (1LL << 31)) return IAK_E_UNSUPPORTED;
+    double mag = 0;
+    for (int i = 0; i < kWe * kHe; i++) {
+        if (!(t.f[i] == t.f[i]) || t.f[i] > 1e30f || t.f[i] < -1e30f) return IAK_E_UNSUPPORTED;
+        mag += t.f[i] < 0 ? -(double)t.f[i] : (double)t.f[i];
+    }
+    if (mag * 255.0 >= 16777216.0) return IAK_E_UNSUPPORTED;  // sums must stay exact in float
+#define TL_CASE(K) case K: return launch_tiled_linear_kw<K>(in, out, W, H, B, in_stride, out_stride, kHe, divisor, avg, t, s);
+    switch (kWe) {
+        TL_CASE(1) TL_CASE(3) TL_CASE(5) TL_CASE(7) TL_CASE(9) TL_CASE(11) TL_CASE(13) TL_CASE(15) TL_CASE(17)
+        TL_CASE(19) TL_CASE(21) TL_CASE(23) TL_CASE(25)
+    default: return IAK_E_UNSUPPORTED;
+    }
+#undef TL_CASE
+}
+
+// ---------------------------------------------------------------------------------------
+// Median, all weights 1, kW x kH <= 255 taps: Huang's sliding histogram, one lane per image
+// column.  A lane keeps the 256-bin histogram of its window in LDS (byte counters packed four
+// to a word, word w of lane l at w * LANES + l so that a lane only ever touches bank l % 32)
+// plus a 16-bin coarse histogram (16 values per bin); moving down one row takes kW pixels
+// out and kW in, and the median is found by one pass over the coarse counts and one over
+// the 16 fine counts of the bin it falls in: O(kW) work per pixel instead of O(kW * kH).
+// The result is the smallest v with #(window <= v) > taps/2, i.e. sorted[taps/2]
+// (imageAnalysis.cu:641-680 with a race-free private window).
+// ---------------------------------------------------------------------------------------
+#define HM_LANES 128
+#define HM_STRIP 64
+#define HM_MAXHALO 24  // kW <= 25
+#define HM_ROWBUF (HM_LANES + HM_MAXHALO + 8)
+__device__ __forceinline__ void hm_update(uint32_t *fine, uint32_t *coarse, uint32_t v, bool add) {
+    // word and byte of value v in the fine table (4 values per word) and of its 16-value bin in
+    // the coarse table; a lane's words are HM_LANES words apart
+    uint32_t f = 1u << ((v << 3) & 24u), c = 1u << ((v >> 1) & 24u);
+    if (!add) { f = 0u - f; c = 0u - c; }  // taking a pixel out adds the two's complement
+    // A lane owns its words, so nothing races; LDS add instructions without a return value are
+    // used because they are fire-and-forget, where a read-modify-write would serialise every
+    // update behind an LDS round trip.
+    atomicAdd(fine + (v >> 2) * HM_LANES, f);
+    atomicAdd(coarse + (v >> 6) * HM_LANES, c);
+}
+// 16 byte counters packed in w[0..3]; `need` (>= 1) is how many more pixels, counted from the
+// first counter, the sought position lies: returns the index of the counter that holds it and
+// in *before the total of the counters in front of that one.  The caller guarantees that the
+// 16 counters together hold at least `need`; totals never exceed 255.
+__device__ __forceinline__ uint32_t hm_find16(const uint32_t w[4], uint32_t need, uint32_t *before) {
+    const uint32_t p0 = w[0] * 0x01010101u, p1 = w[1] * 0x01010101u, p2 = w[2] * 0x01010101u, p3 = w[3] * 0x01010101u;
+    const uint32_t t0 = p0 >> 24, t1 = t0 + (p1 >> 24), t2 = t1 + (p2 >> 24);  // totals through word 0, 1, 2
+    const uint32_t k = (t0 < need ? 1u : 0u) + (t1 < need ? 1u : 0u) + (t2 < need ? 1u : 0u);
+    const uint32_t base = k == 0 ? 0u : (k == 1 ? t0 : (k == 2 ? t1 : t2));
+    const uint32_t p = k == 0 ? p0 : (k == 1 ? p1 : (k == 2 ? p2 : p3));  // byte-wise inclusive prefix sums of word k
+    const uint32_t r = need - base;                                         // 1 <= r <= 255
+    const uint32_t b = ((p & 0xffu) < r ? 1u : 0u) + (((p >> 8) & 0xffu) < r ? 1u : 0u) + (((p >> 16) & 0xffu) < r ? 1u : 0u);
+    *before = base + (((p << 8) >> (8 * b)) & 0xffu);
+    return 4 * k + b;
+}
+
+__global__ __launch_bounds__(HM_LANES) void huang_median_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                                int W, int H, long long in_stride, long long out_stride,
+                                                                int kW, int kH, int strips_x) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hm_lds[];
+    uint32_t *fine = hm_lds + threadIdx.x;                    // [64][LANES]
+    uint32_t *coarse = hm_lds + 64 * HM_LANES + threadIdx.x;  // [4][LANES]
+    // the row that enters and the row that leaves, columns cx0-s .. cx0+LANES-1+s, loaded once
+    // per workgroup and step (double buffered: the next step's rows are fetched a step early)
+    uint8_t *rowbuf = reinterpret_cast<uint8_t *>(hm_lds + 68 * HM_LANES);  // [2 steps][2 rows][HM_ROWBUF]
+    const long long N = (long long)W * H;
+    const uint8_t *src = in + (long long)blockIdx.y * in_stride;
+    uint8_t *dst = out + (long long)blockIdx.y * out_stride;
+    const int a = (kH - 1) / 2, s = (kW - 1) / 2;
+    const int sy = blockIdx.x / strips_x, sx = blockIdx.x - sy * strips_x;
+    const int cx0 = sx * HM_LANES;
+    const int lane = threadIdx.x;
+    const int col = cx0 + lane;
+    const int y0 = sy * HM_STRIP;
+    const int y1 = (y0 + HM_STRIP < H) ? y0 + HM_STRIP : H;
+    const bool live = col < W && !(col < s || col > W - s);  // border columns produce zeros
+#pragma unroll 8
+    for (int w = 0; w < 64; w++) fine[w * HM_LANES] = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) coarse[w * HM_LANES] = 0;
+    const uint32_t need = (uint32_t)(kW * kH) / 2 + 1;  // position of sorted[taps / 2], counted from 1
+    // window of the strip's first row
+    if (live)
+        for (int i = y0 - a; i <= y0 + a; i++)
+            for (int j = col - s; j <= col + s; j++) hm_update(fine, coarse, tap_at(src, N, (long long)i * W + j), true);
+    // rows for the first slide (row y0-a leaves, row y0+1+a enters)
+    const int extra = lane < 2 * s ? HM_LANES + lane : -1;  // the halo columns are fetched by the first 2s lanes
+    uint32_t top0, bot0, top1 = 0, bot1 = 0;
+    {
+        const long long top = (long long)(y0 - a) * W + (cx0 - s), bot = (long long)(y0 + 1 + a) * W + (cx0 - s);
+        top0 = tap_at(src, N, top + lane);
+        bot0 = tap_at(src, N, bot + lane);
+        if (extra >= 0) {
+            top1 = tap_at(src, N, top + extra);
+            bot1 = tap_at(src, N, bot + extra);
+        }
+    }
+    for (int y = y0; y < y1; y++) {
+        uint8_t *rb = rowbuf + ((y - y0) & 1) * (2 * HM_ROWBUF);
+        rb[lane] = (uint8_t)top0;
+        rb[HM_ROWBUF + lane] = (uint8_t)bot0;
+        if (extra >= 0) {
+            rb[extra] = (uint8_t)top1;
+            rb[HM_ROWBUF + extra] = (uint8_t)bot1;
+        }
+        if (y + 2 < y1) {  // fetch the rows of the next slide now, use them after the next barrier
+            const long long top = (long long)(y + 1 - a) * W + (cx0 - s), bot = (long long)(y + 2 + a) * W + (cx0 - s);
+            top0 = tap_at(src, N, top + lane);
+            bot0 = tap_at(src, N, bot + lane);
+            if (extra >= 0) {
+                top1 = tap_at(src, N, top + extra);
+                bot1 = tap_at(src, N, bot + extra);
+            }
+        }
+        uint32_t o = 0;
+        if (live && !(y < a || y > H - a)) {
+            uint32_t cw[4], fw[4], before, unused;
+#pragma unroll
+            for (int w = 0; w < 4; w++) cw[w] = coarse[w * HM_LANES];
+            const uint32_t cb = hm_find16(cw, need, &before);
+#pragma unroll
+            for (int w = 0; w < 4; w++) fw[w] = fine[(cb * 4 + w) * HM_LANES];
+            const uint32_t fb = hm_find16(fw, need - before, &unused);
+            o = cb * 16 + fb;
+        }
+        if (col < W) dst[(long long)y * W + col] = (uint8_t)o;
+        __syncthreads();  // this step's rows are in rowbuf
+        if (live && y + 1 < y1) {
+            for (int j = 0; j < kW; j++) {
+                hm_update(fine, coarse, rb[lane + j], false);
+                hm_update(fine, coarse, rb[HM_ROWBUF + lane + j], true);
+            }
+        }
+    }
+}
+
+static int launch_huang_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+                               long long out_stride, int kW, int kH, hipStream_t s) {
+    if (kW * kH > 255 || (long long)W * H >= (1LL << 31)) return IAK_E_UNSUPPORTED;
+    const int strips_x = (W + HM_LANES - 1) / HM_LANES, strips_y = (H + HM_STRIP - 1) / HM_STRIP;
+    const size_t lds = sizeof(uint32_t) * 68 * HM_LANES + 4 * HM_ROWBUF;
+    hipLaunchKernelGGL(huang_median_kernel, dim3((unsigned)(strips_x * strips_y), B), dim3(HM_LANES), lds, s, in, out, W, H,
+                       in_stride, out_stride, kW, kH, strips_x);
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace iak

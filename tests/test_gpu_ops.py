@@ -248,6 +248,45 @@ def test_linear_generic(ops, kW, kH, W, H):
     each(lambda x: ops.averageFilter(x, k * 9, kW, kH), lambda x: O.average(x, k * 9, kW, kH), imgs)
 
 
+@pytest.mark.parametrize("kW,kH", [(5, 5), (11, 11), (25, 25), (13, 3), (1, 9), (9, 1), (15, 7), (6, 5)])
+@pytest.mark.parametrize("W,H,kind", [(200, 70, "C"), (131, 45, "U"), (64, 33, "K"), (9, 40, "U")])
+def test_linear_tiled(ops, kW, kH, W, H, kind):
+    """Tiles that are cut by the right and bottom edges, windows wider than the image, the
+    wrap-around taps at the row ends, negative and large weights (signed sums, clamping, the
+    average's wrap-around), and weights too large for exact float sums (one-pixel-per-lane path)."""
+    rs = np.random.default_rng(kW * 131 + kH)
+    imgs = batch(kind, W, H, 2)
+    k = (rs.random(kW * kH).astype(np.float32) / (kW * kH) * 1.7)
+    each(lambda x: ops.linearFilter(x, k, kW, kH), lambda x: O.linear(x, k, kW, kH), imgs)
+    each(lambda x: ops.averageFilter(x, k * 9, kW, kH), lambda x: O.average(x, k * 9, kW, kH), imgs)
+    box = np.full(kW * kH, 1.0 / (kW * kH), np.float32)
+    each(lambda x: ops.linearFilter(x, box, kW, kH), lambda x: O.linear(x, box, kW, kH), imgs)
+    signed = ((rs.random(kW * kH) - 0.5) * 4).astype(np.float32)
+    each(lambda x: ops.linearFilter(x, signed, kW, kH), lambda x: O.linear(x, signed, kW, kH), imgs)
+    each(lambda x: ops.averageFilter(x, signed * 50, kW, kH), lambda x: O.average(x, signed * 50, kW, kH), imgs)
+    huge = (rs.random(kW * kH) * 3000).astype(np.float32)
+    each(lambda x: ops.averageFilter(x, huge, kW, kH), lambda x: O.average(x, huge, kW, kH), imgs)
+
+
+@pytest.mark.parametrize("kW,kH", [(5, 5), (7, 7), (15, 15), (3, 9), (9, 3), (1, 5), (5, 1), (15, 17)])
+@pytest.mark.parametrize("W,H,kind", [(200, 70, "C"), (131, 150, "U"), (64, 33, "K"), (300, 20, "C"), (5, 9, "U")])
+def test_median_sliding_histogram(ops, kW, kH, W, H, kind):
+    """All-ones medians larger than 3x3: strips cut by the bottom edge, more than one strip per
+    column (H > 64), more than one workgroup per row (W > 128), windows taller than the image,
+    17x15 = 255 pixels (the counters' limit) on a constant image."""
+    imgs = batch(kind, W, H, 2)
+    if kind == "C":
+        imgs[1, : H // 2] = 0
+    w = [1] * (kW * kH)
+    each(lambda x: ops.medianFilter(x, w, kW, kH), lambda x: O.median(x, w, kW, kH), imgs)
+
+
+def test_median_above_255_taps_uses_bisection(ops):
+    imgs = batch("U", 70, 40, 1)
+    w = [1] * (17 * 17)
+    each(lambda x: ops.medianFilter(x, w, 17, 17), lambda x: O.median(x, w, 17, 17), imgs)
+
+
 @pytest.mark.parametrize("W,H", SIZES + [(768, 568)])
 @pytest.mark.parametrize("kind", KINDS)
 def test_median3(ops, W, H, kind):

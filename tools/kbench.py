@@ -21,7 +21,10 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--kind", default="C")
+    ap.add_argument("--size", default="", help="WxH instead of the bench's 768x568")
     args = ap.parse_args()
+    if args.size:
+        bench.W, bench.H = (int(v) for v in args.size.split("x"))
     B, H, W = args.batch, bench.H, bench.W
     dev = torch.device("cuda")
     rgb = bench.make_cell_batch(B, dev, 1)
@@ -47,6 +50,9 @@ def main():
     kint = np.array([1, 1, 1, 10, 1, 1, 1, 1, 1], np.float32)
     ones = np.ones(9, np.int32)
     cross = np.array([0, 1, 0, 1, 1, 1, 0, 1, 0], np.int32)
+    box11 = np.full(121, 1.0 / 121, np.float32)
+    ones25f = np.ones(25, np.float32)
+    ones49 = np.ones(49, np.int32)
     g, o = gray.data_ptr(), out.data_ptr()
     cases = {
         "copy(torch)": (lambda: out.copy_(gray), 2),
@@ -65,6 +71,12 @@ def main():
         "compass": (lambda: lib.iak_compass(g, o, W, H, B, N, N, st()), 2),
         "erode3": (lambda: lib.iak_erode(g, o, W, H, B, N, N, cross.ctypes.data, 3, 3, st()), 2),
         "dilate3": (lambda: lib.iak_dilate(g, o, W, H, B, N, N, cross.ctypes.data, 3, 3, st()), 2),
+        "linear11_box": (lambda: lib.iak_linear(g, o, W, H, B, N, N, box11.ctypes.data, 11, 11, 0, st()), 2),
+        "average5": (lambda: lib.iak_linear(g, o, W, H, B, N, N, ones25f.ctypes.data, 5, 5, 1, st()), 2),
+        "median7": (lambda: lib.iak_median(g, o, W, H, B, N, N, ones49.ctypes.data, 7, 7, st()), 2),
+        "median5": (lambda: lib.iak_median(g, o, W, H, B, N, N, ones49.ctypes.data, 5, 5, st()), 2),
+        "erode5": (lambda: lib.iak_erode(g, o, W, H, B, N, N, ones49.ctypes.data, 5, 5, st()), 2),
+        "dilate5": (lambda: lib.iak_dilate(g, o, W, H, B, N, N, ones49.ctypes.data, 5, 5, st()), 2),
     }
     only = [x for x in args.only.split(",") if x]
     names = [n for n in cases if not only or n in only]
