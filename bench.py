@@ -52,7 +52,25 @@ KERNEL_OF_GROUP = {
 # The histogram rides on the grayscale pass (the pixel is still in a register), so that kernel's
 # compulsory traffic is the grayscale conversion's alone: 3 bytes read + 1 written per pixel.
 KERNEL_BYTES_PER_PX = {"gray+hist": 4}
-P_A_BYTES_PER_PX = 19  # gray 4, hist 1, equalise 2, gaussian 3, salt-pepper 3, linear 2, median 2, sobel 2
+P_A_BYTES_PER_PX = 19
+# The other two pipelines of the measurement plan; parity-test cases first, available here with
+# --workload for the record (the default line is P-A).
+OP_DILATE, OP_ERODE, OP_OTSU, OP_FEATURES = 9, 10, 12, 15
+P_B = [
+    {"type": OP_LINEAR, "kW": 11, "kH": 11, "fkernel": [1.0 / 121] * 121},
+    {"type": OP_MEDIAN, "kW": 7, "kH": 7, "ikernel": [1] * 49},
+]
+P_C = [
+    {"type": OP_OTSU}, {"type": OP_SOBEL}, {"type": OP_DILATE, "kW": 3, "kH": 3, "ikernel": [1] * 9},
+    {"type": OP_ERODE, "kW": 3, "kH": 3, "ikernel": [0, 1, 0, 1, 1, 1, 0, 1, 0]}, {"type": OP_FEATURES},
+]
+WORKLOADS = {  # name: (ops, W, H, default images per GPU, stage-wise bytes per pixel, description)
+    "P-A": (P_A, 768, 568, 500, 19, "full pipeline (gray, histogram, equalize, gaussian noise, salt-and-pepper 50, "
+            "3x3 linear, 3x3 median, sobel)"),
+    "P-B": (P_B, 4096, 4096, 8, 8, "large-stencil stress (gray, 11x11 linear box, 7x7 median)"),
+    "P-C": (P_C, 768, 568, 500, 14, "segmentation path (gray, histogram, otsu, sobel, 3x3 dilation, 3x3 erosion, "
+            "7 features per image)"),
+}  # gray 4, hist 1, equalise 2, gaussian 3, salt-pepper 3, linear 2, median 2, sobel 2
 
 
 def make_cell_batch(B, device, seed):
@@ -82,7 +100,7 @@ def make_cell_batch(B, device, seed):
     return out
 
 
-def cpu_baseline(rgb_dev, n_threads):
+def cpu_baseline(rgb_dev, n_threads, ops):
     """The CPU oracle (a port of the reference's CUDA kernels, oracle/ia_oracle.c) on a
     bounded sample of the same batch, on this machine's host cores."""
     import oracle_lib as O
@@ -90,7 +108,8 @@ def cpu_baseline(rgb_dev, n_threads):
     x0, x1 = O.xorwow_planes(W * H)
     probe = rgb_dev[:n_threads].cpu().numpy()
     t0 = time.perf_counter()
-    O.pipeline(probe, P_A, x0, x1, threads=n_threads)
+    ops = [o for o in ops if o["type"] != OP_FEATURES]  # the image path; features are checked in the tests
+    O.pipeline(probe, ops, x0, x1, threads=n_threads)
     dt = time.perf_counter() - t0
     per_image_cpu_s = dt * n_threads / probe.shape[0]
     # about 15 s of CPU work in total, at least one image per thread, at most what we hold
@@ -99,11 +118,11 @@ def cpu_baseline(rgb_dev, n_threads):
     n = min(n, rgb_dev.shape[0])
     sample = rgb_dev[:n].cpu().numpy()
     t0 = time.perf_counter()
-    out, _ = O.pipeline(sample, P_A, x0, x1, threads=n_threads)
+    out, _ = O.pipeline(sample, ops, x0, x1, threads=n_threads)
     dt = time.perf_counter() - t0
     return {
         "value": round(n * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "cores": n_threads, "kind": "port",
-        "sample": f"{n} of the batch's 768x568 images, full pipeline, OpenMP over images, {dt:.2f} s wall",
+        "sample": f"{n} of the batch's {W}x{H} images, same pipeline, OpenMP over images, {dt:.2f} s wall",
     }, out, n
 
 
@@ -112,7 +131,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=500, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
+    ap.add_argument("--workload", default="P-A", choices=sorted(WORKLOADS))
     ap.add_argument("--stagewise", action="store_true", help="one pass per operation (no fusion)")
     ap.add_argument("--pointwise", action="store_true", help="fuse per-pixel runs only; stencils stay separate passes")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per GPU (executor streams)")
@@ -134,11 +154,16 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     iak_lib.load()
 
-    B = args.batch
+    global W, H
+    ops, W, H, default_B, bytes_per_px, what = WORKLOADS[args.workload]
+    B = args.batch or default_B
     rgb = make_cell_batch(B, dev, seed=0x1A2B3C4D + rank)
     out = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-    pipe = Pipeline(W, H, B, P_A, fused=False if args.stagewise else ("pointwise" if args.pointwise else True))
+    pipe = Pipeline(W, H, B, ops, fused=False if args.stagewise else ("pointwise" if args.pointwise else True))
     pipe.set_lanes(args.lanes)
+    if any(o["type"] == OP_FEATURES for o in ops):
+        feats = torch.zeros((B, 7), dtype=torch.float32, device=dev)
+        pipe.bind_features(feats)
     hist_local = torch.zeros(256, dtype=torch.int64, device=dev)
     hist_total = torch.zeros(256, dtype=torch.int64, device=dev)
 
@@ -210,12 +235,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"batch of {B} 768x568 RGB cell-like images per GPU, full pipeline "
-                                   "(gray, histogram, equalize, gaussian noise, salt-and-pepper 50, 3x3 linear, "
-                                   "3x3 median, sobel), device-resident",
+            "config": {"workload": f"batch of {B} {W}x{H} RGB cell-like images per GPU, {what}, device-resident",
                        "images_per_gpu": B, "mode": "stagewise" if args.stagewise else ("fused-pointwise" if args.pointwise else "fused"), "lanes": args.lanes,
                        "parallelism": f"image-wise shards x{world}, dataset-histogram all-reduce per step"},
-            "pipeline_frac_of_hbm_roofline": round(value * 1e6 * P_A_BYTES_PER_PX / world / (HBM_PEAK_GBS * 1e9), 4),
+            "pipeline_frac_of_hbm_roofline": round(value * 1e6 * bytes_per_px / world / (HBM_PEAK_GBS * 1e9), 4),
             "groups": [{"name": n, "ms": round(ms, 4), "kernel_ms": round(mm, 4), "images": timed_images,
                         "alg_GBps": round(KERNEL_BYTES_PER_PX.get(n, b) * timed_images * W * H / (mm * 1e-3) / 1e9, 1)
                         if mm > 0 else None}
@@ -225,7 +248,7 @@ def main():
         if not args.no_cpu_baseline:
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
             threads = max(1, min(threads, os.cpu_count() or 1, B))
-            base, ref_out, n = cpu_baseline(rgb, threads)
+            base, ref_out, n = cpu_baseline(rgb, threads, ops)
             # the sample doubles as a full-size parity check of the timed path
             base["matches_gpu"] = bool(np.array_equal(out[:n].cpu().numpy(), ref_out))
             line["cpu_baseline"] = base

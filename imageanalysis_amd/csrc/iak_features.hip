@@ -10,6 +10,7 @@
 // kMeansThresholding (imageAnalysis.cu:281-379): a pixel's label depends on its value only,
 // so each iteration's class sums and counts come from the histogram; the image is touched by
 // one table pass at the end.
+#include "iak_block.hpp"
 #include "iak_chain_stencil.hpp"
 #include "iak_device_fns.hpp"
 #include "iak_common.hpp"
@@ -21,45 +22,42 @@ namespace iak {
 
 #define FEAT_N 7
 
-// One lane per image.  features[b] = {mean, std, area, (perimeter: later), mode, rangeMin, rangeMax};
-// tables[b][0][v] = Otsu mask value of v; counts[b] = 0.
-__global__ __launch_bounds__(64) void features_stats_kernel(const uint32_t *__restrict__ hist, int numPixels, int B,
-                                                            float *__restrict__ features,
-                                                            uint16_t *__restrict__ tables, uint32_t *__restrict__ counts,
-                                                            int32_t *__restrict__ thr_out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const uint32_t *h = hist + (long long)b * 256;
-    float mean, sd;
-    mean_std_from_hist(h, numPixels, &mean, &sd);                // imageMachineLearning.cu:396
-    const int thr = otsu_threshold_from_hist(h, numPixels);     // :399 -> imageAnalysis.cu:255-277
-    long long above = 0;                                          // pixels the mask sets to 255
-    for (int v = 1; v < 256; v++)
-        if (v > thr) above += h[v];
+// One workgroup of 256 lanes per image, lane v = grey value v.
+// features[b] = {mean, std, area, (perimeter: later), mode, rangeMin, rangeMax};
+// tables[b][0][v] = Otsu mask value of v; counts[b] = 0; thr_out[b] = the threshold.
+__global__ __launch_bounds__(256) void features_stats_kernel(const uint32_t *__restrict__ hist, int numPixels, int B,
+                                                             float *__restrict__ features,
+                                                             uint16_t *__restrict__ tables, uint32_t *__restrict__ counts,
+                                                             int32_t *__restrict__ thr_out) {
+    __shared__ BlockScratch bs;
+    const int b = blockIdx.x, v = threadIdx.x;
+    const uint32_t hv = v == 0 ? 0u : hist[(long long)b * 256 + v];  // bin 0 is always empty
+    block_mean_std(hv, numPixels, bs);                            // imageMachineLearning.cu:396
+    const float mean = bs.ms[0], sd = bs.ms[1];
+    block_otsu(hv, numPixels, bs);                                // :399 -> imageAnalysis.cu:255-277
+    const int thr = bs.thr;
+    const long long above = block_sum_ll(v > thr ? (long long)hv : 0, bs.red);  // pixels the mask sets to 255
     const long long rest = (long long)numPixels - above;
-    const long long area = above < rest ? above : rest;          // :353-360
-    int maxVal = 0, mode = -1;                                    // :341-351 (bin 0 is always empty)
-    for (int i = 1; i < 256; i++)
-        if (maxVal < (int)h[i]) {
-            maxVal = (int)h[i];
-            mode = i;
-        }
-    int rmin = -1, rmax = -1;                                     // :379-390
-    for (int i = 1; i < 256; i++)
-        if (h[i] != 0 && rmin == -1) rmin = i;
-    for (int i = 255; i >= 1; i--)
-        if (h[i] != 0 && rmin != -1 && rmax == -1) rmax = i;
-    float *f = features + (long long)b * FEAT_N;
-    f[0] = mean;
-    f[1] = sd;
-    f[2] = (float)(int)area;
-    f[4] = (float)mode;
-    f[5] = (float)rmin;
-    f[6] = (float)rmax;
-    uint16_t *t = tables + (long long)b * CHAIN_MAX * 256;
-    for (int v = 0; v < 256; v++) t[v] = v > thr ? 255 : 0;      // thresholdImage (imageAnalysis.cu:207-216)
-    counts[b] = 0;
-    thr_out[b] = thr;
+    const long long area = above < rest ? above : rest;           // :353-360
+    // mode (:341-351): the first bin with the largest count, -1 when every count is 0;
+    // key = count, then the smaller value wins
+    const long long key = block_max_ll(((long long)hv << 8) | (long long)(255 - v), bs.red);
+    const int mode = (key >> 8) == 0 ? -1 : 255 - (int)(key & 255);
+    // range (:379-390): first and last non-empty bin, -1 when there is none
+    const long long lo_key = block_max_ll(hv ? (long long)(255 - v) : -1, bs.red);
+    const long long hi_key = block_max_ll(hv ? (long long)v : -1, bs.red);
+    tables[(long long)b * CHAIN_MAX * 256 + v] = v > thr ? 255 : 0;  // thresholdImage (imageAnalysis.cu:207-216)
+    if (v == 0) {
+        float *f = features + (long long)b * FEAT_N;
+        f[0] = mean;
+        f[1] = sd;
+        f[2] = (float)(int)area;
+        f[4] = (float)mode;
+        f[5] = lo_key < 0 ? -1.0f : (float)(255 - (int)lo_key);
+        f[6] = hi_key < 0 ? -1.0f : (float)(int)hi_key;
+        counts[b] = 0;
+        thr_out[b] = thr;
+    }
 }
 
 // perimeter = number of 255s in the compass image of the mask (:362-366), from the counter
@@ -204,7 +202,7 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
         if ((rc = iak_hist(img, own_hist, N, B, stride, stream))) return rc;
         hist = own_hist;
     }
-    hipLaunchKernelGGL(features_stats_kernel, dim3((B + 63) / 64), dim3(64), 0, s, hist, (int)N, B, features, tables, counts,
+    hipLaunchKernelGGL(features_stats_kernel, dim3(B), dim3(256), 0, s, hist, (int)N, B, features, tables, counts,
                        thr);
     IAK_LAUNCH_CHECK();
     if (W % 16 == 0 && aligned16(img) && stride % 16 == 0) {

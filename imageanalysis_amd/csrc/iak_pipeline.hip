@@ -12,6 +12,7 @@
 //     previous histogram through the table, not by another pass over the image.
 #include "iak_common.hpp"
 #include "iak_device_fns.hpp"
+#include "iak_block.hpp"
 #include "iak_chain.hpp"
 #include "iak_chain_stencil.hpp"
 #include "iak_stencil_ops.hpp"
@@ -22,28 +23,6 @@
 
 namespace iak {
 
-// block-wide helpers for 256 lanes (4 waves)
-__device__ __forceinline__ long long block_sum_ll(long long v, long long *scratch4) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return scratch4[0] + scratch4[1] + scratch4[2] + scratch4[3];
-}
-
-// inclusive prefix sum over the 256 lanes, wrapping 32-bit arithmetic (as `int` in the reference)
-__device__ __forceinline__ int block_scan_i32(int v, int *buf) {
-    buf[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        int t = (threadIdx.x >= (unsigned)o) ? buf[threadIdx.x - o] : 0;
-        __syncthreads();
-        buf[threadIdx.x] = (int)((unsigned)buf[threadIdx.x] + (unsigned)t);
-        __syncthreads();
-    }
-    return buf[threadIdx.x];
-}
-
 // Per image (one workgroup of 256 lanes, lane v = grey value v): walk the chain once on the
 // histogram, producing every stage's table.  tables: [B][CHAIN_MAX][256] uint16 (LUT stages
 // use the low byte).  Everything that is order-free is done across lanes; the two float
@@ -53,13 +32,10 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *__restr
                                                          ChainDesc d, uint16_t *__restrict__ tables) {
     __shared__ uint32_t h[256];  // current histogram, bin 0 empty
     __shared__ uint32_t h2[256];
-    __shared__ float pdf[256];
-    __shared__ double term[256];
-    __shared__ int ibuf[256];
-    __shared__ int ibuf2[256];
-    __shared__ long long red[4];
+    __shared__ BlockScratch bs;
+    float *pdf = bs.fbuf;
+    long long *red = bs.red;
     __shared__ float ms[2];
-    __shared__ int thr_s;
     const int b = blockIdx.x;
     const int v = threadIdx.x;
     h[v] = hist_in ? hist_in[(long long)b * 256 + v] : 0u;
@@ -71,21 +47,10 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *__restr
         const uint32_t hv = (v == 0) ? 0u : h[v];
         if (st.type == C_GAUSS) {
             if (st.mean == -1 || st.stddev == -1) {
-                // calculateMeanAndStdDev (imageAnalysis.cu:106-128) from the zero-less histogram
-                const long long sum = block_sum_ll((long long)hv * v, red);
-                const long long nonzero = block_sum_ll((long long)hv, red);
-                const float m = (float)sum / (float)numPixels;
-                const double dv = (double)((float)v - m);
-                const long long c = (v == 0) ? ((long long)numPixels - nonzero) : (long long)hv;
-                term[v] = (double)c * (dv * dv);
-                __syncthreads();
+                block_mean_std(hv, numPixels, bs);
                 if (v == 0) {
-                    double acc = 0.0;
-                    for (int i = 0; i < 256; i++) acc += term[i];
-                    const float variance = (float)acc / (float)((long long)numPixels - 1);
-                    const float sd = sqrtf(variance);
-                    ms[0] = m;
-                    ms[1] = sd * sd;  // imageAnalysis.cu:861 passes stdDev * stdDev
+                    ms[0] = bs.ms[0];
+                    ms[1] = bs.ms[1] * bs.ms[1];  // imageAnalysis.cu:861 passes stdDev * stdDev
                 }
             } else if (v == 0) {
                 ms[0] = st.mean;
@@ -113,34 +78,8 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *__restr
             __syncthreads();
             lut = (uint32_t)(int)(pdf[v] * 255) & 0xffu;
         } else if (st.type == C_OTSU) {
-            // Otsu's loop (imageAnalysis.cu:255-277): running sums by prefix scan, the
-            // between-class variance per lane, then the first bin that attains the maximum
-            const long long sum64 = block_sum_ll((long long)hv * v, red);
-            const int sum = (int)sum64;
-            const int nB = block_scan_i32((int)hv, ibuf);
-            const int bSum = block_scan_i32((int)((unsigned)v * hv), ibuf2);
-            const int nF = numPixels - nB;
-            float bcv = -1.0f;
-            if (nB != 0 && nF != 0) {
-                const float bMean = (float)(bSum / nB);
-                const float fMean = (float)((sum - bSum) / nF);
-                bcv = (float)nB * (float)nF * (bMean - fMean) * (bMean - fMean);
-            }
-            __syncthreads();
-            pdf[v] = bcv;
-            __syncthreads();
-            if (v == 0) {
-                float varMax = 0;
-                int t = 0;
-                for (int i = 0; i < 256; i++)
-                    if (pdf[i] > varMax) {
-                        varMax = pdf[i];
-                        t = i;
-                    }
-                thr_s = t;
-            }
-            __syncthreads();
-            lut = (v > thr_s) ? 255u : 0u;
+            block_otsu(hv, numPixels, bs);
+            lut = (v > bs.thr) ? 255u : 0u;
         } else if (st.type == C_KMEANS) {
             // kMeansThresholding (imageAnalysis.cu:281-379) on the histogram; lane v = value v.
             // Label 1 = not nearer to centroid 1 (:298-302); class sums wrap as unsigned int.
