@@ -97,6 +97,8 @@ struct Classes {  // test/test.cu:540-548
 struct Config {
     string image_folder, output_dir, extract_channel, filter;
     bool save_final = false, save_intermediate = false, calc_msqe = false, knn = false;
+    int knn_k = 0;
+    string knn_input;
     Value operations;
     string features_csv;  // "output" of the first feature-extract operation
 };
@@ -119,6 +121,8 @@ Config read_config(const string &path) {
     c.save_intermediate = json["saveIntermediateImages"].asBool();
     c.calc_msqe = json["calc_MSQE"].asBool();
     c.knn = json["knn"].asBool();
+    c.knn_k = json["knnConfig"]["k"].asInt();
+    c.knn_input = json["knnConfig"]["input"].asString();
     c.operations = json["operations"];
     for (size_t i = 0; i < c.operations.size(); i++)
         if (c.operations[i]["type"].asString() == "feature-extract" && c.features_csv.empty())
@@ -192,6 +196,44 @@ int executor_code(const string &type) {
         {"feature-extract", IAK_OP_FEATURES}};
     auto it = m.find(type);
     return it == m.end() ? 0 : it->second;
+}
+
+// test/test.cu:136-173: rows of comma separated floats, shuffled with std::random_shuffle (libc
+// rand()), flattened
+vector<float> read_dataset_csv(int *numAttributes, int *numInstances, const string &path) {
+    std::ifstream csv(path);
+    string line;
+    vector<vector<float>> rows;
+    *numAttributes = 0;
+    while (std::getline(csv, line)) {
+        std::istringstream iss(line);
+        string cell;
+        vector<float> row;
+        while (std::getline(iss, cell, ',')) row.push_back((float)std::stold(cell));
+        if (rows.empty()) *numAttributes = (int)row.size();
+        rows.push_back(row);
+    }
+    // std::random_shuffle as libstdc++ implements it: for i in [1, n): swap(v[i], v[rand() % (i + 1)])
+    for (size_t i = 1; i < rows.size(); i++) std::swap(rows[i], rows[(size_t)rand() % (i + 1)]);
+    *numInstances = (int)rows.size();
+    vector<float> flat;
+    for (auto &r : rows)
+        for (int j = 0; j < *numAttributes; j++) flat.push_back(j < (int)r.size() ? r[j] : 0.0f);
+    return flat;
+}
+
+// test/test.cu:587-597,633-636
+void run_knn(const Config &c) {
+    int numAttributes = 0, numInstances = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    vector<float> data = read_dataset_csv(&numAttributes, &numInstances, c.knn_input);
+    float precision = 0, recall = 0, accuracy = 0;
+    if (numInstances > 0 && numAttributes > 1)
+        accuracy = knnTenfoldCrossVal(data.data(), numInstances, numAttributes, c.knn_k, &precision, &recall);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    printf("Total time required for a tenfold cross validation knn with k of %i on %i instances with %i features: %0.4f ms "
+           "achieved accuracy of %0.4f%%, precision of: %f, and recall of %f\n",
+           c.knn_k, numInstances, (numAttributes > 0) ? numAttributes - 1 : 0, ms, (float)(accuracy * 100.0), precision, recall);
 }
 
 struct Timers {
@@ -531,7 +573,6 @@ int main(int argc, char *argv[]) {
                         "which only the per-image flow produces\n");
         return 2;
     }
-    if (c.knn) printf("knn: the classifier stage is not part of this driver; the feature CSV is written for it\n");
     {
         // The HIP runtime draws from libc rand() while it brings up its first queue.  The k-means
         // of the per-image flow seeds its centroids from rand() and expects the stream of a program
@@ -544,6 +585,7 @@ int main(int argc, char *argv[]) {
         DRV_CHECK(iak_free(warm));
         srand(1);
     }
-    if (force_per_image || needs_per_image) return run_per_image(c, files, ops);
-    return run_batched(c, files, ops, batch_size);
+    const int rc = (force_per_image || needs_per_image) ? run_per_image(c, files, ops) : run_batched(c, files, ops, batch_size);
+    if (rc == 0 && c.knn) run_knn(c);  // after the batch, as the reference does (test/test.cu:587)
+    return rc;
 }

@@ -147,6 +147,82 @@ __global__ void glibc_rand_centroids_kernel(uint32_t *__restrict__ state, int im
     state[34] = pos;
 }
 
+// ---- k-nearest-neighbour prediction (imageMachineLearning.cu:29-156) -------------------------
+// One wave per test instance.  Distance as computeDistances (:29-43): float sum of squared
+// differences over the first A-1 attributes in order, then sqrt; the last attribute is the
+// class.  The reference picks its k candidates with a shared-memory tournament that races and
+// reads one distance per thread slot (:103-140); here the k nearest are taken in (distance,
+// index) order, which is what that code is after.  The vote is the reference's (:54-90),
+// including its always-true tie test, which retries with k-1 down to 1.
+#define KNN_MAX_K 64
+__device__ __forceinline__ float knn_distance(const float *a, const float *b, int A) {
+    float sum = 0;
+    for (int i = 0; i < A - 1; i++) sum += (a[i] - b[i]) * (a[i] - b[i]);
+    return sqrtf(sum);
+}
+// nearer first; equal distances by index; NaN distances last
+__device__ __forceinline__ bool knn_before(float d1, int i1, float d2, int i2) {
+    const bool n1 = d1 != d1, n2 = d2 != d2;
+    if (n1 != n2) return n2;
+    if (!n1 && d1 != d2) return d1 < d2;
+    return i1 < i2;
+}
+__device__ inline int knn_vote(const int *indexes, const float *train, int k, int A) {
+    for (;;) {
+        int classVotes[32];
+        bool duplicate = false;
+        int finalClass = 0, mostVotes = 0;
+        for (int i = 0; i < 32; i++) classVotes[i] = 0;
+        for (int i = 0; i < k; i++) {
+            const int c = (int)train[(long long)indexes[i] * A + A - 1];
+            if (c >= 0 && c < 32) classVotes[c] += 1;  // the reference indexes out of bounds otherwise
+        }
+        for (int i = 0; i < 32; i++)
+            if (classVotes[i] > mostVotes) {
+                finalClass = i;
+                mostVotes = classVotes[i];
+            }
+        for (int i = 0; i < 32; i++)
+            if (classVotes[i] == mostVotes && classVotes[i] > 0) duplicate = true;
+        if (duplicate && (k - 1) > 0) {
+            k = k - 1;
+            continue;
+        }
+        return finalClass;
+    }
+}
+__global__ __launch_bounds__(64) void knn_kernel(const float *__restrict__ train, const float *__restrict__ test, int numTrain,
+                                                 int numTest, int A, int k, int32_t *__restrict__ predictions) {
+    __shared__ int chosen[KNN_MAX_K];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const float *q = test + (long long)t * A;
+    for (int r = 0; r < k; r++) {
+        float best = 0;
+        int best_i = -1;
+        for (int j = lane; j < numTrain; j += 64) {
+            bool taken = false;
+            for (int c = 0; c < r; c++) taken = taken || chosen[c] == j;
+            if (taken) continue;
+            const float d = knn_distance(q, train + (long long)j * A, A);
+            if (best_i < 0 || knn_before(d, j, best, best_i)) {
+                best = d;
+                best_i = j;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float od = __shfl_xor(best, o);
+            const int oi = __shfl_xor(best_i, o);
+            if (oi >= 0 && (best_i < 0 || knn_before(od, oi, best, best_i))) {
+                best = od;
+                best_i = oi;
+            }
+        }
+        if (lane == 0) chosen[r] = best_i;
+        __syncthreads();
+    }
+    if (lane == 0) predictions[t] = knn_vote(chosen, train, k, A);
+}
+
 }  // namespace iak
 
 using namespace iak;
@@ -234,6 +310,17 @@ int iak_kmeans2_map(const uint32_t *hist, int numPixels, int B, const int32_t *i
     if (!hist || !init_centroids || !map || numPixels <= 0 || B <= 0) return IAK_E_ARG;
     hipLaunchKernelGGL(kmeans2_kernel, dim3(B), dim3(64), 0, as_stream(stream), hist, numPixels, B, init_centroids, map,
                        iterations);
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
+int iak_knn_predict(const float *train, const float *test, int numTrain, int numTest, int numAttributes, int k,
+                    int32_t *predictions, void *stream) {
+    if (!train || !test || !predictions || numTrain <= 0 || numTest <= 0 || numAttributes < 1 || k < 1) return IAK_E_ARG;
+    if (k > numTrain) k = numTrain;
+    if (k > KNN_MAX_K) return IAK_E_TOO_LARGE;
+    hipLaunchKernelGGL(knn_kernel, dim3(numTest), dim3(64), 0, as_stream(stream), train, test, numTrain, numTest,
+                       numAttributes, k, predictions);
     IAK_LAUNCH_CHECK();
     return 0;
 }

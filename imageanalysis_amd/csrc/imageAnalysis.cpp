@@ -391,3 +391,70 @@ std::vector<float> extractAllPixelsAsFeatures(Image *image) {
     for (size_t i = 0; i < n; i++) features.push_back(vals[i]);
     return features;
 }
+
+
+// ---- KNN (imageMachineLearning.cu:158-339) -------------------------------------------------------------
+void knn(int numTrain, int numTest, float *train, float *test, int numAttributes, int *h_predictions, int k) {
+    float *d_train = nullptr, *d_test = nullptr;
+    int32_t *d_pred = nullptr;
+    const size_t row = sizeof(float) * (size_t)numAttributes;
+    IAK_CHECK(iak_malloc((void **)&d_train, row * (size_t)numTrain));
+    IAK_CHECK(iak_malloc((void **)&d_test, row * (size_t)numTest));
+    IAK_CHECK(iak_malloc((void **)&d_pred, sizeof(int32_t) * (size_t)numTest));
+    IAK_CHECK(iak_memcpy_h2d(d_train, train, row * (size_t)numTrain, nullptr));
+    IAK_CHECK(iak_memcpy_h2d(d_test, test, row * (size_t)numTest, nullptr));
+    IAK_CHECK(iak_knn_predict(d_train, d_test, numTrain, numTest, numAttributes, k, d_pred, nullptr));
+    IAK_CHECK(iak_memcpy_d2h(h_predictions, d_pred, sizeof(int32_t) * (size_t)numTest, nullptr));
+    IAK_CHECK(iak_free(d_train));
+    IAK_CHECK(iak_free(d_test));
+    IAK_CHECK(iak_free(d_pred));
+}
+
+float knnTenfoldCrossVal(float *dataset, int numInstances, int numAttributes, int k, float *precision, float *recall) {
+    const int NUM_CLASSES = 6;                          // imageMachineLearning.cu:212
+    const int numToRotate = (int)(numInstances * .1);  // :262
+    const int trainSize = numInstances - numToRotate;
+    const size_t total = (size_t)numInstances * (size_t)numAttributes;
+    std::vector<float> rot(total);
+    std::vector<int> predictions((size_t)std::max(numToRotate, 1));
+    double totalAccuracy = 0.0;
+    float totalPrecision = 0, totalRecall = 0;
+    for (int fold = 0; fold < 10; fold++) {
+        const size_t shift = (size_t)numToRotate * (size_t)numAttributes * (size_t)fold;  // std::rotate, :264
+        for (size_t i = 0; i < total; i++) rot[i] = dataset[(i + shift) % total];
+        float accuracy = 0, prec = 0, rec = 0;
+        if (numToRotate > 0) {
+            float *test = rot.data() + (size_t)trainSize * (size_t)numAttributes;
+            knn(trainSize, numToRotate, rot.data(), test, numAttributes, predictions.data(), k);
+            int confusion[NUM_CLASSES * NUM_CLASSES] = {0};  // :214-227; classes outside the matrix are left out
+            for (int i = 0; i < numToRotate; i++) {
+                const int tc = (int)test[(size_t)i * numAttributes + numAttributes - 1], pc = predictions[i];
+                if (tc >= 0 && tc < NUM_CLASSES && pc >= 0 && pc < NUM_CLASSES) confusion[tc * NUM_CLASSES + pc]++;
+            }
+            int ok = 0;
+            for (int i = 0; i < NUM_CLASSES; i++) ok += confusion[i * NUM_CLASSES + i];
+            accuracy = ok / (float)numToRotate;  // :229-236
+            float tp = 0, tr = 0;
+            for (int i = 0; i < NUM_CLASSES; ++i) {  // :239-255
+                int rowSum = 0, colSum = 0;
+                for (int j = 0; j < NUM_CLASSES; ++j) {
+                    colSum += confusion[i + j * NUM_CLASSES];
+                    rowSum += confusion[i * NUM_CLASSES + j];
+                }
+                const int t = confusion[i * NUM_CLASSES + i];
+                tp += (rowSum > 0) ? t / (float)rowSum : 0;
+                tr += (colSum > 0) ? t / (float)colSum : 0;
+            }
+            prec = tp / NUM_CLASSES;
+            rec = tr / NUM_CLASSES;
+        }
+        printf("thread %i had accuracy of %f, precision of %f, and recall of %f\n", fold, (double)accuracy, prec, rec);
+        totalAccuracy += (double)accuracy;
+        totalPrecision += prec;
+        totalRecall += rec;
+    }
+    printf("Average accuracy was %f\n", totalAccuracy / 10.0);
+    *precision = totalPrecision / 10.0;
+    *recall = totalRecall / 10.0;
+    return totalAccuracy / 10.0;
+}

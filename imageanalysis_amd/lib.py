@@ -64,6 +64,7 @@ SIGNATURES = {
     "iak_kmeans2_map": [_vp, _i, _i, _vp, _vp, _vp, _vp],
     "iak_glibc_rand_seed": [_vp, C.c_uint, _vp],
     "iak_glibc_rand_centroids": [_vp, _i, _i, _vp, _vp],
+    "iak_knn_predict": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "iak_pipeline_bind_features": [_vp, _vp],
     "iak_pipeline_create": [C.POINTER(_vp), _i, _i, _i, _vp, _i, C.c_ulonglong, _i],
     "iak_pipeline_destroy": [_vp],

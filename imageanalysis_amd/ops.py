@@ -296,3 +296,14 @@ def featureExtraction(img, hist=None):
                             base, _stream()), "iak_features")
     torch.cuda.current_stream().synchronize()  # ws is freed on return
     return feats if img.dim() == 3 else feats[0]
+
+
+def knn(train, test, k):
+    """imageMachineLearning.cu:158-197 on CUDA float32 tensors [n, numAttributes] (last column =
+    class).  Returns int32 predictions [numTest]."""
+    tr, te = train.contiguous(), test.contiguous()
+    assert tr.dtype == torch.float32 and te.dtype == torch.float32 and tr.shape[1] == te.shape[1]
+    pred = torch.empty((te.shape[0],), dtype=torch.int32, device=tr.device)
+    _l.check(_l.load().iak_knn_predict(tr.data_ptr(), te.data_ptr(), tr.shape[0], te.shape[0], tr.shape[1], int(k),
+                                       pred.data_ptr(), _stream()), "iak_knn_predict")
+    return pred

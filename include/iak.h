@@ -187,6 +187,15 @@ int iak_kmeans2_map(const uint32_t *hist, int numPixels, int B, const int32_t *i
 int iak_glibc_rand_seed(uint32_t *state, unsigned seed, void *stream);
 int iak_glibc_rand_centroids(uint32_t *state, int images, int ops_per_image, int32_t *out, void *stream);
 
+/* k-nearest-neighbour prediction, replaces knn (imageMachineLearning.cu:29-197): rows of
+ * numAttributes floats, the last one the class (an integer in [0, 32)); DEVICE pointers.
+ * Distance = sqrt of the float sum of squared differences over the first numAttributes-1
+ * values; the k nearest are taken in (distance, index) order (the reference's tournament
+ * races); the vote is the reference's, whose tie test always fires and retries with k-1, so
+ * the prediction is the nearest row's class.  k is cut to numTrain; k <= 64. */
+int iak_knn_predict(const float *train, const float *test, int numTrain, int numTest, int numAttributes,
+                    int k, int32_t *predictions, void *stream);
+
 /* ---- batched pipeline executor ------------------------------------------------------------
  * Replaces the per-image / per-operation loop of executeOperations (test/test.cu:266-564)
  * for a whole batch that is resident on the device: grayscale (luminance) + histogram,

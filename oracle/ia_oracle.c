@@ -712,3 +712,114 @@ void iao_pipeline_ex(const uint8_t *rgb, uint8_t *out, int W, int H, int B, cons
         free(tmp);
     }
 }
+
+
+/* ---- k-nearest neighbours (imageMachineLearning.cu:29-339) ----------------------------
+ * PARITY UNPINNED, more than elsewhere: the reference's selection kernel races, reads one
+ * distance per thread slot (:109-112) and lets thread 1 vote; its cross-validation passes
+ * `dataset + trainSize` as the test rows (:275-276; rows are numAttributes floats wide).
+ * Restated here as what the code is evidently after: the k nearest rows in (distance, index)
+ * order, the vote exactly as written (:54-90), the test fold = the last tenth of the rotated
+ * rows.  NUM_CLASSES is 6 (:212); rows whose class falls outside are left out of the
+ * confusion matrix instead of written out of bounds. */
+static int knn_before(float d1, int i1, float d2, int i2) {
+    int n1 = d1 != d1, n2 = d2 != d2;
+    if (n1 != n2) return n2;
+    if (!n1 && d1 != d2) return d1 < d2;
+    return i1 < i2;
+}
+static int knn_vote_ref(const int *indexes, const float *train, int k, int A) {
+    int classVotes[32];
+    int duplicate = 0, finalClass = 0, mostVotes = 0;
+    for (int i = 0; i < 32; i++) classVotes[i] = 0;
+    for (int i = 0; i < k; i++) {
+        int c = (int)train[(long)indexes[i] * A + A - 1];
+        if (c >= 0 && c < 32) classVotes[c] += 1;
+    }
+    for (int i = 0; i < 32; i++)
+        if (classVotes[i] > mostVotes) {
+            finalClass = i;
+            mostVotes = classVotes[i];
+        }
+    for (int i = 0; i < 32; i++)
+        if (classVotes[i] == mostVotes && classVotes[i] > 0) duplicate = 1;
+    if (duplicate && (k - 1) > 0) return knn_vote_ref(indexes, train, k - 1, A); /* :83-88 */
+    return finalClass;
+}
+void iao_knn_predict(const float *train, const float *test, int numTrain, int numTest, int A, int k, int *pred) {
+    if (k > numTrain) k = numTrain;
+    float *dist = (float *)malloc(sizeof(float) * (size_t)numTrain);
+    int *order = (int *)malloc(sizeof(int) * (size_t)numTrain);
+    for (int t = 0; t < numTest; t++) {
+        for (int j = 0; j < numTrain; j++) { /* computeDistances :29-43 */
+            float sum = 0;
+            for (int a = 0; a < A - 1; a++)
+                sum += (test[(long)t * A + a] - train[(long)j * A + a]) * (test[(long)t * A + a] - train[(long)j * A + a]);
+            dist[j] = (float)sqrt(sum);
+            order[j] = j;
+        }
+        for (int r = 0; r < k; r++) { /* selection of the r-th nearest */
+            int m = r;
+            for (int j = r + 1; j < numTrain; j++)
+                if (knn_before(dist[order[j]], order[j], dist[order[m]], order[m])) m = j;
+            int tmp = order[r];
+            order[r] = order[m];
+            order[m] = tmp;
+        }
+        pred[t] = knn_vote_ref(order, train, k, A);
+    }
+    free(dist);
+    free(order);
+}
+
+#define IAO_NUM_CLASSES 6
+float iao_knn_crossval(const float *dataset, int numInstances, int A, int k, float *precision, float *recall,
+                       float *fold_accuracy) {
+    int numToRotate = (int)(numInstances * .1); /* :262 */
+    int trainSize = numInstances - numToRotate;
+    float *rot = (float *)malloc(sizeof(float) * (size_t)numInstances * A);
+    int *pred = (int *)malloc(sizeof(int) * (size_t)(numToRotate > 0 ? numToRotate : 1));
+    double totalAccuracy = 0.0;
+    float totalPrecision = 0, totalRecall = 0;
+    for (int fold = 0; fold < 10; fold++) {
+        long shift = (long)numToRotate * A * fold; /* std::rotate to the left, :264 */
+        long total = (long)numInstances * A;
+        for (long i = 0; i < total; i++) rot[i] = dataset[(i + shift) % total];
+        float accuracy = 0, prec = 0, rec = 0;
+        if (numToRotate > 0) {
+            const float *test = rot + (long)trainSize * A;
+            iao_knn_predict(rot, test, trainSize, numToRotate, A, k, pred);
+            int confusion[IAO_NUM_CLASSES * IAO_NUM_CLASSES];
+            memset(confusion, 0, sizeof confusion);
+            for (int i = 0; i < numToRotate; i++) { /* :214-227 */
+                int tc = (int)test[(long)i * A + A - 1], pc = pred[i];
+                if (tc >= 0 && tc < IAO_NUM_CLASSES && pc >= 0 && pc < IAO_NUM_CLASSES) confusion[tc * IAO_NUM_CLASSES + pc]++;
+            }
+            int ok = 0;
+            for (int i = 0; i < IAO_NUM_CLASSES; i++) ok += confusion[i * IAO_NUM_CLASSES + i];
+            accuracy = ok / (float)numToRotate; /* :229-236 */
+            float tp = 0, tr = 0;
+            for (int i = 0; i < IAO_NUM_CLASSES; i++) { /* :239-255 */
+                int row = 0, col = 0;
+                for (int j = 0; j < IAO_NUM_CLASSES; j++) {
+                    col += confusion[i + j * IAO_NUM_CLASSES];
+                    row += confusion[i * IAO_NUM_CLASSES + j];
+                }
+                int t = confusion[i * IAO_NUM_CLASSES + i];
+                tp += (row > 0) ? t / (float)row : 0;
+                tr += (col > 0) ? t / (float)col : 0;
+            }
+            prec = tp / IAO_NUM_CLASSES;
+            rec = tr / IAO_NUM_CLASSES;
+        }
+        if (fold_accuracy) fold_accuracy[fold] = accuracy;
+        totalAccuracy += (double)accuracy;
+        totalPrecision += prec;
+        totalRecall += rec;
+    }
+    free(rot);
+    free(pred);
+    *precision = totalPrecision / 10.0;
+    *recall = totalRecall / 10.0;
+    return (float)(totalAccuracy / 10.0); /* :337-338 */
+}

@@ -146,4 +146,11 @@ void iao_pipeline_ex(const uint8_t *rgb, uint8_t *out, int W, int H, int B,
 #ifdef __cplusplus
 }
 #endif
+/* k-nearest neighbours (imageMachineLearning.cu:29-339); see the notes at the definitions:
+ * parity with the reference is unpinned here more than anywhere (its kernels race). */
+void iao_knn_predict(const float *train, const float *test, int numTrain, int numTest,
+                     int numAttributes, int k, int *predictions);
+float iao_knn_crossval(const float *dataset, int numInstances, int numAttributes, int k,
+                       float *precision, float *recall, float *fold_accuracy10);
+
 #endif

@@ -78,6 +78,9 @@ def lib():
     L.iao_pipeline.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.POINTER(IaoOp), C.c_int,
                                C.c_void_p, C.c_void_p, i64p, C.c_int]
     L.iao_pipeline_ex.argtypes = L.iao_pipeline.argtypes + [C.c_void_p, C.c_void_p]
+    L.iao_knn_predict.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p]
+    L.iao_knn_crossval.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
+    L.iao_knn_crossval.restype = C.c_float
     _lib = L
     return L
 
@@ -287,6 +290,22 @@ def make_ops(ops):
         arr[i].mean = o.get("mean", -1.0)
         arr[i].stddev = o.get("stddev", -1.0)
     return arr, keep
+
+
+def knn_predict(train, test, k):
+    train = np.ascontiguousarray(train, np.float32)
+    test = np.ascontiguousarray(test, np.float32)
+    pred = np.zeros(test.shape[0], np.int32)
+    lib().iao_knn_predict(train.reshape(-1), test.reshape(-1), train.shape[0], test.shape[0], train.shape[1], int(k), pred)
+    return pred
+
+
+def knn_crossval(dataset, k):
+    """Returns (accuracy, precision, recall, per-fold accuracies)."""
+    d = np.ascontiguousarray(dataset, np.float32)
+    p, r, folds = np.zeros(1, np.float32), np.zeros(1, np.float32), np.zeros(10, np.float32)
+    acc = lib().iao_knn_crossval(d.reshape(-1), d.shape[0], d.shape[1], int(k), p, r, folds)
+    return float(acc), float(p[0]), float(r[0]), folds
 
 
 _libc = None

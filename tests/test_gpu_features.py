@@ -87,3 +87,63 @@ def test_features_single_image_and_strided_batch(ops):
     for b in range(4):
         assert np.array_equal(got[b], O.features(imgs[b]))
     assert np.array_equal(one, O.features(imgs[2]))
+
+
+def _dataset(n, A, classes, seed, ties=False):
+    rs = np.random.default_rng(seed)
+    X = rs.normal(0, 1, (n, A - 1)).astype(np.float32) * 10
+    y = rs.integers(0, classes, n)
+    X += y[:, None].astype(np.float32) * 6          # separable-ish clusters
+    if ties:
+        X = np.round(X / 8) * 8                     # many exactly equal distances
+    return np.concatenate([X, y[:, None].astype(np.float32)], axis=1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n_train,n_test,A,k,ties", [(300, 40, 8, 3, False), (50, 7, 8, 1, False), (130, 33, 4, 5, True),
+                                                     (5, 3, 8, 9, False), (700, 20, 2, 64, True)])
+def test_knn_matches_oracle(ops, n_train, n_test, A, k, ties):
+    train = _dataset(n_train, A, 5, 11 + n_train, ties)
+    test = _dataset(n_test, A, 5, 12 + n_test, ties)
+    if ties:
+        test[: min(5, n_test)] = train[:5][: min(5, n_test)]      # zero distances, duplicated rows
+        train[7 % n_train] = train[3 % n_train]
+    got = ops.knn(torch.from_numpy(train).cuda(), torch.from_numpy(test).cuda(), k).cpu().numpy()
+    assert np.array_equal(got, O.knn_predict(train, test, k))
+
+
+def test_knn_crossval_through_the_driver(tmp_path):
+    """The driver's knn stage: reads the CSV, shuffles it with rand() as the reference does,
+    runs the ten folds and prints the reference's report line."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = _dataset(203, 8, 5, 99)
+    csv = tmp_path / "features.csv"
+    csv.write_text("".join(",".join(repr(float(v)) for v in row[:-1]) + f",{int(row[-1])}\n" for row in data))
+    (tmp_path / "in").mkdir()
+    cfg = {"image_folder": str(tmp_path / "in"), "input_image_filter": "", "saveIntermediateImages": False,
+           "saveFinalImages": False, "calc_MSQE": False, "output_dir": str(tmp_path), "extract_channel": "grey",
+           "operations": [], "knn": True, "knnConfig": {"k": 3, "input": str(csv)}}
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    r = subprocess.run([os.path.join(root, "imageanalysis_amd", "lib", "ia_driver"), str(tmp_path / "cfg.json")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # the same shuffle here: srand(1) state, swap(v[i], v[rand() % (i + 1)])
+    import ctypes as C
+    libc = C.CDLL("libc.so.6")
+    libc.rand.restype = C.c_int
+    libc.srand(1)
+    rows = [np.array([np.float32(float(c)) for c in l.split(",")], np.float32) for l in csv.read_text().splitlines()]
+    for i in range(1, len(rows)):
+        j = libc.rand() % (i + 1)
+        rows[i], rows[j] = rows[j], rows[i]
+    acc, prec, rec, folds = O.knn_crossval(np.stack(rows), 3)
+    lines = r.stdout.splitlines()
+    fold_lines = [l for l in lines if l.startswith("thread ")]
+    assert len(fold_lines) == 10
+    for f, l in enumerate(fold_lines):
+        assert l.startswith(f"thread {f} had accuracy of {folds[f]:f},"), (l, folds[f])
+    assert f"Average accuracy was {np.float64(np.sum(folds.astype(np.float64)) / 10.0):f}" in lines
+    last = [l for l in lines if l.startswith("Total time required for a tenfold cross validation knn with k of 3 on 203 instances with 7 features")]
+    assert len(last) == 1 and f"achieved accuracy of {np.float32(acc * 100.0):0.4f}%, precision of: {prec:f}, and recall of {rec:f}" in last[0]
