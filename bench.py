@@ -43,7 +43,8 @@ P_A = [
 # launch group -> the HIP kernel that does its image pass (names as rocprofv3 prints them)
 KERNEL_OF_GROUP = {
     "gray+hist": "iak::gray_kernel<0, true, true>",
-    "equalize+gauss+salt_pepper+linear": "iak::chain_stencil8_kernel<iak::Lin8Swar>",
+    "equalize+gauss+salt_pepper+linear+median+sobel": "iak::strip_kernel",
+    "equalize+gauss+salt_pepper+linear": "iak::chain_stencil8_kernel<iak::Lin8Swar, false>",
     "equalize+gauss+salt_pepper": "iak::chain_apply_kernel<true>",
     "linear": "iak::stencil8_kernel<iak::Lin8Swar, 8>",
     "median": "iak::stencil8_kernel<iak::Median8, 8>",
@@ -135,6 +136,7 @@ def main():
     ap.add_argument("--workload", default="P-A", choices=sorted(WORKLOADS))
     ap.add_argument("--stagewise", action="store_true", help="one pass per operation (no fusion)")
     ap.add_argument("--pointwise", action="store_true", help="fuse per-pixel runs only; stencils stay separate passes")
+    ap.add_argument("--strips", action="store_true", help="also fuse runs of 3x3 stencils through LDS strips")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per GPU (executor streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -159,7 +161,7 @@ def main():
     B = args.batch or default_B
     rgb = make_cell_batch(B, dev, seed=0x1A2B3C4D + rank)
     out = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-    pipe = Pipeline(W, H, B, ops, fused=False if args.stagewise else ("pointwise" if args.pointwise else True))
+    pipe = Pipeline(W, H, B, ops, fused=False if args.stagewise else ("pointwise" if args.pointwise else ("strips" if args.strips else True)))
     pipe.set_lanes(args.lanes)
     if any(o["type"] == OP_FEATURES for o in ops):
         feats = torch.zeros((B, 7), dtype=torch.float32, device=dev)
@@ -236,7 +238,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"batch of {B} {W}x{H} RGB cell-like images per GPU, {what}, device-resident",
-                       "images_per_gpu": B, "mode": "stagewise" if args.stagewise else ("fused-pointwise" if args.pointwise else "fused"), "lanes": args.lanes,
+                       "images_per_gpu": B, "mode": "stagewise" if args.stagewise else ("fused-pointwise" if args.pointwise else ("fused-strips" if args.strips else "fused")), "lanes": args.lanes,
                        "parallelism": f"image-wise shards x{world}, dataset-histogram all-reduce per step"},
             "pipeline_frac_of_hbm_roofline": round(value * 1e6 * bytes_per_px / world / (HBM_PEAK_GBS * 1e9), 4),
             "groups": [{"name": n, "ms": round(ms, 4), "kernel_ms": round(mm, 4), "images": timed_images,

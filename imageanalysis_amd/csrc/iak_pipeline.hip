@@ -15,6 +15,7 @@
 #include "iak_block.hpp"
 #include "iak_chain.hpp"
 #include "iak_chain_stencil.hpp"
+#include "iak_strip.hpp"
 #include "iak_stencil_ops.hpp"
 
 #include <new>
@@ -178,15 +179,16 @@ struct OpCopy {
     std::vector<int> i;
 };
 
-enum GroupKind { G_GRAYHIST, G_HIST, G_CHAIN, G_OP, G_CHAIN_OP, G_FEATURES };
+enum GroupKind { G_GRAYHIST, G_HIST, G_CHAIN, G_OP, G_CHAIN_OP, G_FEATURES, G_STRIP };
 
 struct Group {
     GroupKind kind;
     std::string name;
     long long alg_bytes;  // algorithmic bytes per pixel of the operations in the group
     int op_index = -1;    // G_OP
-    ChainDesc chain;      // G_CHAIN
+    ChainDesc chain;      // G_CHAIN, G_CHAIN_OP, G_STRIP (n == 0: no per-pixel run in front)
     bool chain_needs_hist = false;
+    StripDesc strip;      // G_STRIP
 };
 
 // operators the fused chain+stencil kernel can take over (the 8-pixel 3x3 family)
@@ -289,6 +291,34 @@ static void free_all(iak_pipeline *p) {
     for (auto st : p->aux) (void)hipStreamDestroy(st);
 }
 
+// A run of 3x3 stencils starting at operation i that one strip pass can take: at least two,
+// at most three, no dilation (see iak_strip.hpp).  Fills g->strip and returns the
+// number of operations taken, 0 if there is no such run.
+static int take_strip(const iak_pipeline *p, int i, Group *g) {
+    const int n = (int)p->ops.size();
+    if (p->mode != IAK_PIPE_FUSED_STRIPS || (long long)p->W * p->H >= (1LL << 30)) return 0;
+    int run = 0;
+    StripOp so[SK_MAX_STAGES];
+    while (i + run < n && run < SK_MAX_STAGES) {
+        const iak_op &o = p->ops[i + run].op;
+        if (!is_fusable_stencil(o) || o.type == IAK_OP_DILATE) break;
+        if (!strip_op_from(o, &so[run])) break;
+        run++;
+    }
+    while (run >= 2 && strip_rows(p->W, run) == 0) run--;
+    if (run < 2) return 0;
+    g->strip.S = run;
+    g->strip.TH = strip_rows(p->W, run);
+    g->strip.n = 4;
+    for (int k = 0; k < run; k++) {
+        g->strip.op[k] = so[k];
+        g->alg_bytes += op_alg_bytes(p->ops[i + k].op.type);
+        if (!g->name.empty()) g->name += "+";
+        g->name += op_name(p->ops[i + k].op.type);
+    }
+    return run;
+}
+
 static int plan(iak_pipeline *p) {
     p->groups.clear();
     Group g0;
@@ -371,8 +401,13 @@ static int plan(iak_pipeline *p) {
                 gh.alg_bytes = 1;
                 p->groups.push_back(gh);
             }
-            // the stencil right after the chain reads the chain's output from LDS instead of memory
-            if (p->mode == IAK_PIPE_FUSED && i < n && p->W % 16 == 0 && (long long)p->W * p->H < (1LL << 30) && is_fusable_stencil(p->ops[i].op)) {
+            // a run of stencils right after the chain: one strip pass for the chain and all of them
+            if (const int taken = take_strip(p, i, &g)) {
+                g.kind = G_STRIP;
+                i += taken;
+            } else
+            // a single stencil right after the chain reads the chain's output from LDS instead of memory
+            if ((p->mode == IAK_PIPE_FUSED || p->mode == IAK_PIPE_FUSED_STRIPS) && i < n && p->W % 16 == 0 && (long long)p->W * p->H < (1LL << 30) && is_fusable_stencil(p->ops[i].op)) {
                 g.kind = G_CHAIN_OP;
                 g.op_index = i;
                 g.alg_bytes += op_alg_bytes(p->ops[i].op.type);
@@ -382,6 +417,18 @@ static int plan(iak_pipeline *p) {
             p->groups.push_back(g);
             hist_known = false;  // conservative: a later consumer re-measures
             continue;
+        }
+        {
+            Group gs;
+            gs.alg_bytes = 0;
+            gs.chain.n = 0;
+            if (const int taken = take_strip(p, i, &gs)) {
+                gs.kind = G_STRIP;
+                p->groups.push_back(gs);
+                hist_known = false;
+                i += taken;
+                continue;
+            }
         }
         Group g;
         g.kind = o.type == IAK_OP_FEATURES ? G_FEATURES : G_OP;
@@ -406,7 +453,9 @@ extern "C" {
 int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op *ops, int nops,
                         unsigned long long seed, int mode) {
     if (!out || W <= 0 || H <= 0 || maxB <= 0 || nops < 0 || (nops > 0 && !ops)) return IAK_E_ARG;
-    if (mode != IAK_PIPE_STAGEWISE && mode != IAK_PIPE_FUSED && mode != IAK_PIPE_FUSED_POINTWISE) return IAK_E_ARG;
+    if (mode != IAK_PIPE_STAGEWISE && mode != IAK_PIPE_FUSED && mode != IAK_PIPE_FUSED_POINTWISE &&
+        mode != IAK_PIPE_FUSED_STRIPS)
+        return IAK_E_ARG;
     iak_pipeline *p = new (std::nothrow) iak_pipeline();
     if (!p) return (int)hipErrorOutOfMemory;
     p->W = W; p->H = H; p->maxB = maxB; p->mode = mode;
@@ -723,6 +772,30 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             case IAK_OP_DILATE: { Dilate8 op; op.mask = se_mask3(o.ikernel); rc = go(op); break; }
             default: rc = IAK_E_UNSUPPORTED; break;
             }
+            cur_hist = nullptr;
+            break;
+        }
+        case G_STRIP: {
+            const ChainDesc cd = chain_for(p, g.chain, b0);
+            if (cd.n) {
+                bool wants = false;
+                for (int k = 0; k < cd.n; k++)
+                    wants = wants || cd.st[k].type == C_EQUALIZE || cd.st[k].type == C_OTSU || cd.st[k].type == C_KMEANS ||
+                            (cd.st[k].type == C_GAUSS && (cd.st[k].mean == -1 || cd.st[k].stddev == -1));
+                if (wants && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
+                for (int k = 0; k < cd.n; k++)
+                    if (cd.st[k].plane && cd.st[k].type != C_KMEANS && !aligned16(cd.st[k].plane)) return IAK_E_UNSUPPORTED;
+                hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables);
+                IAK_LAUNCH_CHECK();
+                if (ev) {
+                    p->split[gi] = 1;
+                    IAK_HIP(hipEventRecord(ev[2 * gi + 1], s));
+                }
+            } else if (ev) {
+                p->split[gi] = 0;
+            }
+            if (!aligned16(cur) || (reinterpret_cast<uintptr_t>(dst) & 7u)) return IAK_E_UNSUPPORTED;
+            rc = launch_strip(cur, dst, p->W, p->H, B, N, N, cd, sl.tables, g.strip, s);
             cur_hist = nullptr;
             break;
         }
