@@ -130,8 +130,8 @@ def cpu_baseline(rgb_dev, n_threads, ops):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
     ap.add_argument("--workload", default="P-A", choices=sorted(WORKLOADS))
     ap.add_argument("--stagewise", action="store_true", help="one pass per operation (no fusion)")
@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--strips", action="store_true", help="also fuse runs of 3x3 stencils through LDS strips")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per GPU (executor streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel events in the timed steps (no roofline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -167,20 +168,22 @@ def main():
         feats = torch.zeros((B, 7), dtype=torch.float32, device=dev)
         pipe.bind_features(feats)
     hist_local = torch.zeros(256, dtype=torch.int64, device=dev)
-    hist_total = torch.zeros(256, dtype=torch.int64, device=dev)
 
     def step():
+        # the batch's grayscale histogram is added to hist_local by the run; across GPUs the
+        # dataset-level histogram is the one exchange of the path (2 KiB, latency-bound)
         hist_local.zero_()
         pipe.run(rgb, out=out, hist_sum=hist_local)
         if dist is not None:
-            # dataset-level histogram: the one exchange of the path (2 KiB, latency-bound)
             dist.all_reduce(hist_local, op=dist.ReduceOp.SUM)
-        hist_total.copy_(hist_local)
 
     for _ in range(args.warmup):
         step()
-    slots = min(max(args.steps, 1), 256)
-    pipe.set_timing(slots)
+    # per-kernel HIP events on a sample of the timed steps (every 8th, at least one): each timed
+    # step pays about 20 us for its ten event records
+    every = 1 if args.steps < 16 else 8
+    nrec = 0 if args.no_events else min((args.steps + every - 1) // every, 256)
+    pipe.set_timing(nrec, every=every)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -197,7 +200,6 @@ def main():
         dt = float(t.item())
 
     # per-launch-group durations from the HIP events recorded inside the timed steps
-    nrec = min(args.steps, slots)
     acc = None
     for sl in range(nrec):
         t = pipe.timings(sl)

@@ -271,6 +271,8 @@ struct iak_pipeline {
     // 2 main kernel first.
     std::vector<int> split;
     int slots = 0;
+    int every = 1;            // only every `every`-th run records events
+    long long runs_seen = 0;  // runs since set_timing
     std::vector<hipEvent_t> ev;
     long long runs_timed = 0;
 
@@ -551,8 +553,15 @@ int iak_pipeline_destroy(iak_pipeline *p) {
     return 0;
 }
 
+int iak_pipeline_set_timing_every(iak_pipeline *p, int every) {
+    if (!p || every < 1) return IAK_E_ARG;
+    p->every = every;
+    return 0;
+}
+
 int iak_pipeline_set_timing(iak_pipeline *p, int slots) {
     if (!p || slots < 0 || slots > 1024) return IAK_E_ARG;
+    p->runs_seen = 0;
     for (auto e : p->ev) (void)hipEventDestroy(e);
     p->ev.clear();
     p->slots = 0;
@@ -846,7 +855,8 @@ int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, u
     if (!p || !rgb || !out || B <= 0 || B > p->maxB) return IAK_E_ARG;
     hipStream_t s = as_stream(stream);
     const int ng = (int)p->groups.size();
-    const hipEvent_t *ev = p->slots ? p->ev.data() + (size_t)(p->runs_timed % p->slots) * (2 * ng + 1) : nullptr;
+    const bool timed = p->slots && (p->runs_seen++ % p->every) == 0;
+    const hipEvent_t *ev = timed ? p->ev.data() + (size_t)(p->runs_timed % p->slots) * (2 * ng + 1) : nullptr;
     const int lanes = (p->lanes > B) ? B : p->lanes;
     p->run_B = B;
     if (p->n_kmeans) {  // this run's rand() draws, two per image per k-means operation, in image order

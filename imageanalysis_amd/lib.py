@@ -72,6 +72,7 @@ SIGNATURES = {
     "iak_pipeline_set_lanes": [_vp, _i],
     "iak_pipeline_timed_images": [_vp],
     "iak_pipeline_set_timing": [_vp, _i],
+    "iak_pipeline_set_timing_every": [_vp, _i],
     "iak_pipeline_timings": [_vp, _i, _vp, _vp, _vp, _vp, _i],
 }
 _RESTYPE = {"iak_error_string": C.c_char_p, "iak_features_workspace_bytes": C.c_longlong}

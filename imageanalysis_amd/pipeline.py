@@ -130,8 +130,10 @@ class Pipeline:
     def timed_images(self):
         return _l.load().iak_pipeline_timed_images(self._h)
 
-    def set_timing(self, slots):
-        """Record per-group HIP events for the next runs, into `slots` rotating sets."""
+    def set_timing(self, slots, every=1):
+        """Record per-group HIP events for the next runs (every `every`-th of them), into `slots`
+        rotating sets."""
+        _l.check(_l.load().iak_pipeline_set_timing_every(self._h, int(every)), "iak_pipeline_set_timing_every")
         _l.check(_l.load().iak_pipeline_set_timing(self._h, int(slots)), "iak_pipeline_set_timing")
 
     def groups(self):

@@ -271,6 +271,10 @@ int iak_pipeline_timed_images(iak_pipeline *p);
  * compulsory traffic of the operations in the group).  ms and main_ms may both be NULL to
  * query names only.  Returns the number of groups, or a negative error. */
 int iak_pipeline_set_timing(iak_pipeline *p, int slots);
+/* Records events only on every `every`-th run after set_timing (default 1: all of them), so that
+ * a long measurement pays for the event records on a sample of its runs only; slot numbers
+ * count the timed runs. */
+int iak_pipeline_set_timing_every(iak_pipeline *p, int every);
 int iak_pipeline_timings(iak_pipeline *p, int slot, float *ms, float *main_ms, const char **names,
                          long long *alg_bytes_per_px, int cap);
 

@@ -171,6 +171,14 @@ def test_pipeline_timings(Pipeline):
         "equalize+gauss+salt_pepper", "linear", "median", "sobel"]
     assert sum(r[2] for r in t) == 19  # stage-wise compulsory bytes per pixel of this pipeline
     assert all(r[1] >= 0 and 0 <= r[3] <= r[1] + 1e-3 for r in t)
+    # events on every third run only: five runs leave two timed ones
+    from imageanalysis_amd.lib import IakError
+    p.set_timing(4, every=3)
+    for _ in range(5):
+        p.run(rgb)
+    assert len(p.timings(1)) == len(t)
+    with pytest.raises(IakError):
+        p.timings(2)
 
 
 P_C_FEATURES = P_C + [{"type": O.OP_FEATURES}]
