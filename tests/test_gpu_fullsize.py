@@ -1,0 +1,112 @@
+"""BASELINE.json's full sizes.  A few images of each configuration are compared with the oracle
+directly; the whole batch is checked through size-independent properties (histogram totals,
+lookup-table structure, order relations between morphology results, idempotence)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import synth
+
+pytestmark = pytest.mark.gpu
+
+GAUSS16 = [1 / 16, 2 / 16, 1 / 16, 2 / 16, 4 / 16, 2 / 16, 1 / 16, 2 / 16, 1 / 16]
+ONES9 = [1] * 9
+P_A = [
+    {"type": O.OP_EQUALIZE}, {"type": O.OP_GAUSS, "mean": -1.0, "stddev": -1.0}, {"type": O.OP_SALT_PEPPER, "iparam": 50},
+    {"type": O.OP_LINEAR, "kW": 3, "kH": 3, "fkernel": GAUSS16}, {"type": O.OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": ONES9},
+    {"type": O.OP_SOBEL},
+]
+
+
+@pytest.fixture(scope="module")
+def mods():
+    assert torch.cuda.is_available()
+    from imageanalysis_amd import ops
+    from imageanalysis_amd.pipeline import Pipeline
+    return ops, Pipeline
+
+
+def test_config2_batch_500_of_768x568(mods):
+    """Config 2: the bench's batch shape.  Images 0, 249 and 499 against the oracle, the rest
+    through the dataset histogram (every pixel of every image is counted exactly once)."""
+    ops, Pipeline = mods
+    import bench
+    W, H, B = 768, 568, 500
+    bench.W, bench.H = W, H
+    rgb = bench.make_cell_batch(B, torch.device("cuda"), seed=77)
+    p = Pipeline(W, H, B, P_A)
+    hist_sum = torch.zeros(256, dtype=torch.int64, device="cuda")
+    gray_hist = torch.empty((B, 256), dtype=torch.int32, device="cuda")
+    out = p.run(rgb, hist_sum=hist_sum, gray_hist=gray_hist)
+    torch.cuda.synchronize()
+    x0, x1 = O.xorwow_planes(W * H)
+    pick = [0, 249, 499]
+    want, _ = O.pipeline(rgb[pick].cpu().numpy(), P_A, x0, x1, threads=3)
+    assert np.array_equal(out[pick].cpu().numpy(), want)
+    # histogram of the grayscale images: per image it misses only the zeros, and the batch sum is the sum of the rows
+    gh = gray_hist.cpu().numpy().astype(np.int64)
+    assert np.array_equal(gh.sum(axis=0), hist_sum.cpu().numpy())
+    gray = ops.convertRGBToGrayscale(rgb)
+    zeros = (gray == 0).sum(dim=(1, 2)).cpu().numpy()
+    assert np.array_equal(gh.sum(axis=1) + zeros, np.full(B, W * H))
+    assert np.all(gh[:, 0] == 0)
+    # Sobel output: top row and left column are border zeros in every image
+    assert int(out[:, 0, :].max()) == 0 and int(out[:, :, 0].max()) == 0
+
+
+def test_config2_properties_on_the_whole_batch(mods):
+    ops, _ = mods
+    import bench
+    W, H, B = 768, 568, 500
+    bench.W, bench.H = W, H
+    rgb = bench.make_cell_batch(B, torch.device("cuda"), seed=78)
+    gray = ops.convertRGBToGrayscale(rgb)
+    # equalisation maps are non-decreasing and the equalised image is the map applied
+    hist = ops.calculateHistogram(gray)
+    m = ops.equalizeHistogram(hist, W * H)
+    assert bool((m[:, 1:] >= m[:, :-1]).all()) and int(m.max()) <= 255 and int(m.min()) >= 0
+    eq = ops.equalizeImageWithHist(gray, m)
+    b = 123
+    assert torch.equal(eq[b], m[b].to(torch.uint8)[gray[b].long()])
+    # thresholding is idempotent; Otsu's mask is a threshold mask of the same image
+    mask, thr = ops.otsuThresholdImage(gray, return_threshold=True)
+    assert torch.equal(ops.thresholdImage(mask, 0), mask)
+    assert torch.equal(mask[b], ((gray[b].int() > int(thr[b])) * 255).to(torch.uint8))
+    # morphology order: erosion keeps or clears pixels, dilation of a mask covers the interior of the mask
+    er = ops.imageErosion(mask, ONES9, 3, 3)
+    assert bool(((er == 0) | (er == mask)).all())
+    di = ops.imageDilation(mask, ONES9, 3, 3)
+    assert bool((di[:, 1:-1, 1:-1] >= mask[:, 1:-1, 1:-1]).all())
+    # the 3x3 median of a two-valued image stays two-valued; of a constant interior it is the constant
+    med = ops.medianFilter(mask, ONES9, 3, 3)
+    assert bool(((med == 0) | (med == 255)).all())
+    const = torch.full((4, H, W), 77, dtype=torch.uint8, device="cuda")
+    assert int(ops.medianFilter(const, ONES9, 3, 3)[:, 1:, 1:].min()) == 77
+    # noise is the same field for every image: where salt-and-pepper changed image 0 it changed image b the same way
+    rng = ops.Randomness(W * H)
+    sp = ops.saltAndPepperNoise(gray, rng, 50)
+    changed = (sp[0] != gray[0]) | (sp[b] != gray[b])
+    hit = ((sp[0] == 0) | (sp[0] == 255)) & ((sp[b] == 0) | (sp[b] == 255))
+    assert bool((hit | ~changed).all())
+    frac = float(((sp == 0) | (sp == 255)).float().mean())
+    assert 0.015 < frac < 0.03          # 1 / 50.999999 of the pixels, plus the few that were 0 / 255 already
+
+
+def test_config4_4096_square_large_windows(mods):
+    """Config 4: one 4096x4096 image against the oracle (11x11 box linear filter, 7x7 median);
+    the median's idempotence on its own two-valued output for the rest of the batch."""
+    ops, Pipeline = mods
+    W = H = 4096
+    rgb = synth.rgb_batch("C", W, H, 1)
+    ops_pb = [{"type": O.OP_LINEAR, "kW": 11, "kH": 11, "fkernel": [1.0 / 121] * 121},
+              {"type": O.OP_MEDIAN, "kW": 7, "kH": 7, "ikernel": [1] * 49}]
+    p = Pipeline(W, H, 2, ops_pb)
+    both = torch.from_numpy(np.concatenate([rgb, rgb[:, :, ::-1, :].copy()])).cuda()
+    got = p.run(both).cpu().numpy()
+    want, _ = O.pipeline(rgb, ops_pb, threads=1)
+    assert np.array_equal(got[0], want[0])
+    # a vertically flipped image is a different input: its result must differ from the first, and
+    # re-running reproduces it
+    assert not np.array_equal(got[1], got[0])
+    assert np.array_equal(p.run(both).cpu().numpy(), got)
