@@ -13,7 +13,7 @@
 //   --per-image  the reference's own flow, call for call, through imageAnalysis.h: one image
 //                at a time, one allocation per operation, previous image freed by the driver.
 //                Chosen automatically when the config asks for what only that flow has:
-//                intermediate images, a colour channel instead of grayscale, the MSQE report.
+//                intermediate images, the MSQE report.
 //   --check-config  parse the config, list and decode the input files, write nothing, touch
 //                no GPU.
 //
@@ -418,6 +418,12 @@ int run_batched(const Config &c, const vector<string> &files, vector<Op> &ops, i
         plan.push_back(o);
         has_features = has_features || code == IAK_OP_FEATURES;
     }
+    const int input = c.extract_channel == "grey" ? IAK_INPUT_LUMINANCE : c.extract_channel == "red" ? IAK_INPUT_RED
+                      : c.extract_channel == "green" ? IAK_INPUT_GREEN : c.extract_channel == "blue" ? IAK_INPUT_BLUE : -1;
+    if (input < 0) {  // test/test.cu:319-322
+        printf("Unsupported color option: %s\n", c.extract_channel.c_str());
+        exit(-10);
+    }
     Classes classes;
     vector<vector<float>> dataset;
     vector<int> labels;
@@ -486,6 +492,7 @@ int run_batched(const Config &c, const vector<string> &files, vector<Op> &ops, i
             L->H = img.height;
             const size_t N = (size_t)L->W * L->H;
             DRV_CHECK(iak_pipeline_create(&L->pipe, L->W, L->H, batch_size, plan.data(), (int)plan.size(), 1234ULL, IAK_PIPE_FUSED));
+            DRV_CHECK(iak_pipeline_set_input(L->pipe, input));
             DRV_CHECK(iak_malloc((void **)&L->d_rgb, 3 * N * (size_t)batch_size));
             DRV_CHECK(iak_malloc((void **)&L->d_out, N * (size_t)batch_size));
             L->h_rgb.resize(3 * N * (size_t)batch_size);
@@ -567,10 +574,10 @@ int main(int argc, char *argv[]) {
         printf("%zu of %zu files readable, %zu operations\n", ok, files.size(), ops.size());
         return 0;
     }
-    const bool needs_per_image = c.save_intermediate || c.extract_channel != "grey" || c.calc_msqe;
+    const bool needs_per_image = c.save_intermediate || c.calc_msqe;
     if (force_batch && needs_per_image) {
-        fprintf(stderr, "--batch: the config asks for intermediate images, a colour channel or the MSQE report, "
-                        "which only the per-image flow produces\n");
+        fprintf(stderr, "--batch: the config asks for intermediate images or the MSQE report, which only the per-image "
+                        "flow produces\n");
         return 2;
     }
     {

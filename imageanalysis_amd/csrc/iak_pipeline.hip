@@ -235,6 +235,7 @@ long long op_alg_bytes(int t) {
 
 struct iak_pipeline {
     int W = 0, H = 0, maxB = 0, mode = 0;
+    int input = IAK_INPUT_LUMINANCE;
     long long N = 0;
     std::vector<OpCopy> ops;
     std::vector<Group> groups;
@@ -711,7 +712,9 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
         int rc = 0;
         switch (g.kind) {
         case G_GRAYHIST:
-            rc = iak_gray_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, 0, s);
+            rc = p->input <= IAK_INPUT_AVERAGE
+                     ? iak_gray_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input, s)
+                     : iak_channel_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input - IAK_INPUT_RED, s);
             if (ev) p->split[gi] = hist_sum ? 2 : 0;
             if (rc == 0 && hist_sum) {
                 if (ev) IAK_HIP(hipEventRecord(ev[2 * gi + 1], s));
@@ -839,6 +842,14 @@ int iak_pipeline_set_lanes(iak_pipeline *p, int lanes) {
         p->fork_join.push_back(e);
     }
     p->lanes = lanes;
+    return 0;
+}
+
+int iak_pipeline_set_input(iak_pipeline *p, int input) {
+    if (!p || input < IAK_INPUT_LUMINANCE || input > IAK_INPUT_BLUE) return IAK_E_ARG;
+    p->input = input;
+    p->groups[0].name = input <= IAK_INPUT_AVERAGE ? "gray+hist" : "channel+hist";
+    p->groups[0].alg_bytes = input <= IAK_INPUT_AVERAGE ? 4 + 1 : 2 + 1;
     return 0;
 }
 

@@ -204,6 +204,7 @@ __device__ __forceinline__ uint32_t gray4(uint32_t r, uint32_t g, uint32_t b) {
     for (int k = 0; k < 4; k++) {
         uint32_t y = METHOD == 0 ? lum1(byte_of(r, k), byte_of(g, k), byte_of(b, k))
                                  : avg1(byte_of(r, k), byte_of(g, k), byte_of(b, k));
+        if (METHOD == 2) y = byte_of(r, k);  // one plane as it is (the G and B loads are dead code)
         o |= (y & 0xffu) << (8 * k);
     }
     return o;
@@ -233,8 +234,11 @@ __global__ __launch_bounds__(GRAY_THREADS) void gray_kernel(const uint8_t *__res
             const long long o0 = c << 4;
             const bool two = c + nthreads < nchunks;
             const long long o1 = two ? ((c + nthreads) << 4) : o0;
-            const u32x4 r0 = ld16<IAK_NT_GRAY_LD>(R + o0), g0 = ld16<IAK_NT_GRAY_LD>(G + o0), b0 = ld16<IAK_NT_GRAY_LD>(Bp + o0);
-            const u32x4 r1 = ld16<IAK_NT_GRAY_LD>(R + o1), g1 = ld16<IAK_NT_GRAY_LD>(G + o1), b1 = ld16<IAK_NT_GRAY_LD>(Bp + o1);
+            // METHOD 2 reads one plane only (the other two pointers may lie past the batch)
+            const u32x4 r0 = ld16<IAK_NT_GRAY_LD>(R + o0);
+            const u32x4 g0 = METHOD == 2 ? r0 : ld16<IAK_NT_GRAY_LD>(G + o0), b0 = METHOD == 2 ? r0 : ld16<IAK_NT_GRAY_LD>(Bp + o0);
+            const u32x4 r1 = ld16<IAK_NT_GRAY_LD>(R + o1);
+            const u32x4 g1 = METHOD == 2 ? r1 : ld16<IAK_NT_GRAY_LD>(G + o1), b1 = METHOD == 2 ? r1 : ld16<IAK_NT_GRAY_LD>(Bp + o1);
             u32x4 y0, y1;
 #pragma unroll
             for (int w = 0; w < 4; w++) y0[w] = gray4<METHOD>(r0[w], g0[w], b0[w]);
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(GRAY_THREADS) void gray_kernel(const uint8_t *__res
         scalar_from = nchunks << 4;
     }
     for (long long t = scalar_from + tid; t < N; t += nthreads) {
-        uint32_t y = METHOD == 0 ? lum1(R[t], G[t], Bp[t]) : avg1(R[t], G[t], Bp[t]);
+        uint32_t y = METHOD == 2 ? R[t] : (METHOD == 0 ? lum1(R[t], G[t], Bp[t]) : avg1(R[t], G[t], Bp[t]));
         dst[t] = (uint8_t)y;
         if (HIST) atomicAdd(&sh[(y & 0xff) * HIST_COLS + col], 1u);
     }
@@ -326,12 +330,10 @@ using namespace iak;
 
 extern "C" {
 
-int iak_gray_hist(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B, long long rgb_stride,
-                  long long gray_stride, int method, void *stream) {
-    if (!rgb || !gray || W <= 0 || H <= 0 || B <= 0) return IAK_E_ARG;
-    if (method != 0 && method != 1) return IAK_E_ARG;
+// method 0 / 1: the two grayscale conversions; 2: the plane at `rgb` copied as it is
+static int gray_launch(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B, long long rgb_stride,
+                       long long gray_stride, int method, void *stream) {
     const long long N = (long long)W * H;
-    if (rgb_stride < 3 * N || gray_stride < N) return IAK_E_ARG;
     const bool vec = aligned16(rgb) && aligned16(gray) && rgb_stride % 16 == 0 && gray_stride % 16 == 0 && N % 16 == 0;
     hipStream_t s = as_stream(stream);
     dim3 block(GRAY_THREADS);
@@ -346,17 +348,37 @@ int iak_gray_hist(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int 
         dim3 grid((unsigned)bx, B);
 #define GH(M, V) hipLaunchKernelGGL((gray_kernel<M, true, V>), grid, block, 0, s, rgb, gray, hist, N, rgb_stride, gray_stride)
         if (method == 0) { if (vec) GH(0, true); else GH(0, false); }
-        else { if (vec) GH(1, true); else GH(1, false); }
+        else if (method == 1) { if (vec) GH(1, true); else GH(1, false); }
+        else { if (vec) GH(2, true); else GH(2, false); }
 #undef GH
     } else {
         dim3 grid(blocks_x(vec ? N / 32 : N, GRAY_THREADS, B, 2048), B);
 #define GN(M, V) hipLaunchKernelGGL((gray_kernel<M, false, V>), grid, block, 0, s, rgb, gray, (uint32_t *)nullptr, N, rgb_stride, gray_stride)
         if (method == 0) { if (vec) GN(0, true); else GN(0, false); }
-        else { if (vec) GN(1, true); else GN(1, false); }
+        else if (method == 1) { if (vec) GN(1, true); else GN(1, false); }
+        else { if (vec) GN(2, true); else GN(2, false); }
 #undef GN
     }
     IAK_LAUNCH_CHECK();
     return 0;
+}
+
+int iak_gray_hist(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B, long long rgb_stride,
+                  long long gray_stride, int method, void *stream) {
+    if (!rgb || !gray || W <= 0 || H <= 0 || B <= 0) return IAK_E_ARG;
+    if (method != 0 && method != 1) return IAK_E_ARG;
+    const long long N = (long long)W * H;
+    if (rgb_stride < 3 * N || gray_stride < N) return IAK_E_ARG;
+    return gray_launch(rgb, gray, hist, W, H, B, rgb_stride, gray_stride, method, stream);
+}
+
+int iak_channel_hist(const uint8_t *rgb, uint8_t *out, uint32_t *hist, int W, int H, int B, long long rgb_stride,
+                     long long out_stride, int channel, void *stream) {
+    if (!rgb || !out || W <= 0 || H <= 0 || B <= 0) return IAK_E_ARG;
+    if (channel < 0 || channel > 2) return IAK_E_ARG;
+    const long long N = (long long)W * H;
+    if (rgb_stride < 3 * N || out_stride < N) return IAK_E_ARG;
+    return gray_launch(rgb + (long long)channel * N, out, hist, W, H, B, rgb_stride, out_stride, 2, stream);
 }
 
 int iak_gray(const uint8_t *rgb, uint8_t *gray, int W, int H, int B, long long rgb_stride, long long gray_stride,

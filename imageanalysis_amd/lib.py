@@ -13,6 +13,7 @@ IAK_PIPE_STAGEWISE, IAK_PIPE_FUSED, IAK_PIPE_FUSED_POINTWISE, IAK_PIPE_FUSED_STR
 (IAK_OP_EQUALIZE, IAK_OP_GAUSS, IAK_OP_SALT_PEPPER, IAK_OP_LINEAR, IAK_OP_AVERAGE, IAK_OP_MEDIAN, IAK_OP_SOBEL,
  IAK_OP_COMPASS, IAK_OP_DILATE, IAK_OP_ERODE, IAK_OP_THRESHOLD, IAK_OP_OTSU, IAK_OP_QUANTIZE, IAK_OP_KMEANS,
  IAK_OP_FEATURES) = range(1, 16)
+IAK_INPUT_LUMINANCE, IAK_INPUT_AVERAGE, IAK_INPUT_RED, IAK_INPUT_GREEN, IAK_INPUT_BLUE = range(5)
 IAK_N_FEATURES = 7
 IAK_GLIBC_RAND_WORDS = 35
 
@@ -37,6 +38,7 @@ SIGNATURES = {
     "iak_device_count": [C.POINTER(_i)],
     "iak_set_device": [_i],
     "iak_gray": [_vp, _vp, _i, _i, _i, _ll, _ll, _i, _vp],
+    "iak_channel_hist": [_vp, _vp, _vp, _i, _i, _i, _ll, _ll, _i, _vp],
     "iak_gray_hist": [_vp, _vp, _vp, _i, _i, _i, _ll, _ll, _i, _vp],
     "iak_hist": [_vp, _vp, _ll, _i, _ll, _vp],
     "iak_eq_map": [_vp, _vp, _i, _i, _vp],
@@ -66,6 +68,7 @@ SIGNATURES = {
     "iak_glibc_rand_centroids": [_vp, _i, _i, _vp, _vp],
     "iak_knn_predict": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "iak_pipeline_bind_features": [_vp, _vp],
+    "iak_pipeline_set_input": [_vp, _i],
     "iak_pipeline_create": [C.POINTER(_vp), _i, _i, _i, _vp, _i, C.c_ulonglong, _i],
     "iak_pipeline_destroy": [_vp],
     "iak_pipeline_run": [_vp, _vp, _vp, _i, _vp, _vp, _vp],

@@ -123,6 +123,12 @@ class Pipeline:
         self._features = features  # keep it alive
         _l.check(_l.load().iak_pipeline_bind_features(self._h, features.data_ptr()), "iak_pipeline_bind_features")
 
+    def set_input(self, what):
+        """What the first pass makes of the RGB input: "grey" (luminance, default), "average",
+        "red", "green" or "blue" (the driver's extract_channel)."""
+        code = {"grey": 0, "gray": 0, "average": 1, "red": 2, "green": 3, "blue": 4}[what]
+        _l.check(_l.load().iak_pipeline_set_input(self._h, code), "iak_pipeline_set_input")
+
     def set_lanes(self, lanes):
         """Run every batch as `lanes` concurrent sub-batches (see iak_pipeline_set_lanes)."""
         _l.check(_l.load().iak_pipeline_set_lanes(self._h, int(lanes)), "iak_pipeline_set_lanes")

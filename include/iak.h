@@ -63,6 +63,12 @@ int iak_gray(const uint8_t *rgb, uint8_t *gray, int W, int H, int B,
 int iak_gray_hist(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B,
                   long long rgb_stride, long long gray_stride, int method, void *stream);
 
+/* One colour plane of every image copied out, with its histogram (hist may be NULL): the batched
+ * form of extractSingleColorChannel (imageAnalysis.cu:72-92; channel 0 = R, 1 = G, 2 = B, planar
+ * layout) followed by copyHostImageToDevice and calculateHistogram (test/test.cu:296-327). */
+int iak_channel_hist(const uint8_t *rgb, uint8_t *out, uint32_t *hist, int W, int H, int B,
+                     long long rgb_stride, long long out_stride, int channel, void *stream);
+
 /* ---- histogram / equalisation / look-up family -------------------------------------
  * Replaces calculateHistogram + calcHistogram (imageAnalysis.cu:130-152): value 0 is
  * never counted.  hist[B][256] is fully overwritten. */
@@ -245,6 +251,14 @@ typedef struct iak_pipeline iak_pipeline;
 int iak_pipeline_create(iak_pipeline **p, int W, int H, int maxB, const iak_op *ops, int nops,
                         unsigned long long seed, int mode);
 int iak_pipeline_destroy(iak_pipeline *p);
+/* What the first pass makes of the RGB input (the driver's extract_channel, test/test.cu:276-322):
+ * luminance grayscale (default), the (R+G+B)/3 grayscale, or one colour plane. */
+#define IAK_INPUT_LUMINANCE 0
+#define IAK_INPUT_AVERAGE 1
+#define IAK_INPUT_RED 2
+#define IAK_INPUT_GREEN 3
+#define IAK_INPUT_BLUE 4
+int iak_pipeline_set_input(iak_pipeline *p, int input);
 /* rgb: B planar RGB images (stride 3*W*H); out: B result images (stride W*H).
  * hist_sum: DEVICE array of 256 uint64, or NULL; the batch's grayscale-image histogram
  * (bin 0 empty) is ADDED to it -- the dataset histogram a multi-GPU job all-reduces.

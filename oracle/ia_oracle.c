@@ -635,11 +635,12 @@ void iao_features(const uint8_t *in, int W, int H, float *feat) {
 
 static void run_ops_one(const uint8_t *rgb, uint8_t *out, int W, int H, const iao_op *ops, int nops,
                         const uint32_t *x0, const uint32_t *x1, int *hist, uint8_t *tmp, const int *centroids,
-                        float *features) {
+                        float *features, int input) {
     long N = (long)W * H;
     uint8_t *cur = out, *nxt = tmp;
     int kmeans_seen = 0;
-    iao_gray(rgb, cur, W, H, 0);
+    if (input <= 1) iao_gray(rgb, cur, W, H, input); /* test.cu:276-287 */
+    else memcpy(cur, rgb + (size_t)(input - 2) * N, (size_t)N); /* extractSingleColorChannel, test.cu:288-318 */
     iao_hist(cur, N, hist);
     for (int i = 0; i < nops; i++) {
         const iao_op *op = &ops[i];
@@ -682,12 +683,12 @@ static void run_ops_one(const uint8_t *rgb, uint8_t *out, int W, int H, const ia
 
 void iao_pipeline(const uint8_t *rgb, uint8_t *out, int W, int H, int B, const iao_op *ops, int nops,
                   const uint32_t *x0, const uint32_t *x1, long long *hist_sum, int threads) {
-    iao_pipeline_ex(rgb, out, W, H, B, ops, nops, x0, x1, hist_sum, threads, NULL, NULL);
+    iao_pipeline_ex(rgb, out, W, H, B, ops, nops, x0, x1, hist_sum, threads, NULL, NULL, 0);
 }
 
 void iao_pipeline_ex(const uint8_t *rgb, uint8_t *out, int W, int H, int B, const iao_op *ops, int nops,
                      const uint32_t *x0, const uint32_t *x1, long long *hist_sum, int threads, const int *centroids,
-                     float *features) {
+                     float *features, int input) {
     long N = (long)W * H;
     int nk = 0;
     for (int i = 0; i < nops; i++) nk += ops[i].type == IAO_OP_KMEANS;
@@ -702,7 +703,8 @@ void iao_pipeline_ex(const uint8_t *rgb, uint8_t *out, int W, int H, int B, cons
         for (int b = 0; b < B; b++) {
             int hist[256];
             run_ops_one(rgb + (size_t)b * 3 * N, out + (size_t)b * N, W, H, ops, nops, x0, x1, hist, tmp,
-                        centroids ? centroids + (size_t)b * 2 * nk : NULL, features ? features + (size_t)b * 7 : NULL);
+                        centroids ? centroids + (size_t)b * 2 * nk : NULL, features ? features + (size_t)b * 7 : NULL,
+                        input);
             for (int v = 0; v < 256; v++) local[v] += hist[v];
         }
         if (hist_sum) {

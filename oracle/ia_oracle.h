@@ -138,10 +138,13 @@ void iao_pipeline(const uint8_t *rgb, uint8_t *out, int W, int H, int B,
  * centroids[(b * nk + k) * 2 + {0,1}], the random(0,256) draws (imageAnalysis.cu:39-41,
  * 359-361) of image b's k-th k-means operation, nk = number of such operations;
  * IAO_OP_FEATURES (test/test.cu:533-555) leaves the image alone and writes
- * features[b * 7 ..] (imageMachineLearning.cu:393-415). */
+ * features[b * 7 ..] (imageMachineLearning.cu:393-415).
+ * input: what the driver makes of the RGB image first (test/test.cu:276-322): 0 luminance
+ * grayscale, 1 (R+G+B)/3, 2 / 3 / 4 the red / green / blue plane. */
 void iao_pipeline_ex(const uint8_t *rgb, uint8_t *out, int W, int H, int B,
                      const iao_op *ops, int nops, const uint32_t *x0, const uint32_t *x1,
-                     long long *hist_sum, int threads, const int *centroids, float *features);
+                     long long *hist_sum, int threads, const int *centroids, float *features,
+                     int input);
 
 #ifdef __cplusplus
 }

@@ -77,7 +77,7 @@ def lib():
     L.iao_features.argtypes = [u8p, C.c_int, C.c_int, f32p]
     L.iao_pipeline.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.POINTER(IaoOp), C.c_int,
                                C.c_void_p, C.c_void_p, i64p, C.c_int]
-    L.iao_pipeline_ex.argtypes = L.iao_pipeline.argtypes + [C.c_void_p, C.c_void_p]
+    L.iao_pipeline_ex.argtypes = L.iao_pipeline.argtypes + [C.c_void_p, C.c_void_p, C.c_int]
     L.iao_knn_predict.argtypes = [f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, i32p]
     L.iao_knn_crossval.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p]
     L.iao_knn_crossval.restype = C.c_float
@@ -324,7 +324,7 @@ def libc_random_0_256(n, skip=0):
     return np.asarray(vals[skip:], np.int32)
 
 
-def pipeline_ex(rgb, ops, x0=None, x1=None, threads=1, centroids=None):
+def pipeline_ex(rgb, ops, x0=None, x1=None, threads=1, centroids=None, input=0):
     """As pipeline(); ops may hold OP_KMEANS (centroids: int32 [B, nk, 2], the rand() draws in
     the reference's order) and OP_FEATURES.  Returns (out, hist, features [B, 7])."""
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
@@ -337,7 +337,7 @@ def pipeline_ex(rgb, ops, x0=None, x1=None, threads=1, centroids=None):
     lib().iao_pipeline_ex(rgb.reshape(-1), out.reshape(-1), W, H, B, arr, len(ops),
                           x0.ctypes.data if x0 is not None else None,
                           x1.ctypes.data if x1 is not None else None, hs, threads,
-                          cen.ctypes.data if cen is not None else None, feats.ctypes.data)
+                          cen.ctypes.data if cen is not None else None, feats.ctypes.data, input)
     del keep
     return out, hs, feats
 

@@ -98,3 +98,14 @@ def test_driver_intermediates_use_the_reference_names(folder):
     assert np.array_equal(gray, O.gray(rgb[2], 0))
     check_outputs(out, want, feats)
     assert "Total time spent k Means thresholding images" in stdout
+
+
+@pytest.mark.parametrize("mode", [["--batch"], ["--per-image"]])
+def test_driver_colour_channel(folder, mode):
+    d, rgb, _, _ = folder
+    tag = "green" + mode[0].strip("-")
+    out, _ = run_driver(d, mode, tag, {"extract_channel": "green"})
+    x0, x1 = O.xorwow_planes(W * H)
+    cent = O.libc_random_0_256(2 * len(NAMES)).reshape(len(NAMES), 1, 2)
+    want, _, feats = O.pipeline_ex(rgb, OPS, x0, x1, centroids=cent, input=3)
+    check_outputs(out, want, feats)

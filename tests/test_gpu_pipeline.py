@@ -226,3 +226,25 @@ def test_pipeline_features_need_a_bound_array(Pipeline):
     p = Pipeline(64, 48, 2, [{"type": O.OP_FEATURES}])
     with pytest.raises(IakError):
         p.run(torch.zeros((2, 3, 48, 64), dtype=torch.uint8, device="cuda"))
+
+
+@pytest.mark.parametrize("what,code", [("average", 1), ("red", 2), ("green", 3), ("blue", 4)])
+@pytest.mark.parametrize("W,H", [(64, 48), (37, 23)])
+def test_pipeline_input_modes(Pipeline, what, code, W, H):
+    """The driver's extract_channel: a colour plane (or the averaging grayscale) instead of the
+    luminance grayscale as the pipeline's input; the histograms follow."""
+    B = 3
+    rgb = synth.rgb_batch("U", W, H, B)
+    x0, x1 = O.xorwow_planes(W * H)
+    want, want_hist, _ = O.pipeline_ex(rgb, P_A, x0, x1, input=code)
+    p = Pipeline(W, H, B, P_A)
+    p.set_input(what)
+    hs = torch.zeros(256, dtype=torch.int64, device="cuda")
+    gh = torch.empty((B, 256), dtype=torch.int32, device="cuda")
+    got = p.run(torch.from_numpy(rgb).cuda(), hist_sum=hs, gray_hist=gh).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.array_equal(hs.cpu().numpy(), want_hist)
+    first = rgb[:, code - 2] if code >= 2 else None
+    if first is not None:
+        for b in range(B):
+            assert np.array_equal(gh[b].cpu().numpy(), O.hist(first[b]))
