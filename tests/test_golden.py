@@ -108,6 +108,10 @@ def test_gpu_hits_golden(name):
     eq(ops.imageErosion(otsu, CROSS, 3, 3), "erode_cross")
     eq(ops.imageDilation(otsu, ONES, 3, 3), "dilate_ones")
     eq(ops.imageErosion(g, ONES, 3, 3), "erode_ones_gray")
+    cent = torch.tensor([[215, 101]], dtype=torch.int32, device="cuda")  # the first two draws of an unseeded rand()
+    eq(ops.kMeansThresholding(g, cent), "kmeans_215_101")
+    assert tuple(ops.LibcRand().centroids(1).cpu().numpy().reshape(-1)) == (215, 101)
+    eq(ops.featureExtraction(g), "features")
 
 
 @pytest.mark.gpu
