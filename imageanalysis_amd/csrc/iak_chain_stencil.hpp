@@ -44,25 +44,36 @@ __global__ __launch_bounds__(CS_THREADS) void chain_stencil8_kernel(const uint8_
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
 
-    // phase 1: stage chain(input) for rows y0-1 .. y0+TH, columns x0-16 .. x0+TW+15
+    // phase 1: stage chain(input) for rows y0-1 .. y0+TH, columns x0-16 .. x0+TW+15.
+    // Chunk c of the tile is (row c / cpr, 16-byte column c % cpr); a lane takes chunks
+    // tid, tid + T, tid + 2T, ... two at a time.  The division is done once: afterwards row,
+    // column, flat image offset and tile offset advance by additions (32-bit: W*H < 2^31).
     const int cpr = pitch >> 4;  // 16-byte chunks per tile row
     const int nchunks = (TH + 2) * cpr;
+    const int step_r = CS_THREADS / cpr, step_k = CS_THREADS - step_r * cpr;  // one stride of T chunks
+    const int Ni = (int)N;
+    int r0 = (int)threadIdx.x / cpr, k0 = (int)threadIdx.x - r0 * cpr;
+    int f0 = (y0 - 1 + r0) * W + (x0 - 16 + 16 * k0);  // flat offset of the chunk in the image (may be < 0 or >= N)
+    int t0 = r0 * pitch + 16 * k0;                     // its offset in the tile
+    const int df_row = W - 16 * cpr, dt_row = pitch - 16 * cpr;  // correction when the column wraps to the next row
     for (int c = threadIdx.x; c < nchunks; c += 2 * CS_THREADS) {
-        const int c1 = c + CS_THREADS;
-        const int r0 = c / cpr, k0 = c - r0 * cpr;
-        const int r1 = c1 / cpr, k1 = c1 - r1 * cpr;
-        const long long f0 = (long long)(y0 - 1 + r0) * W + (x0 - 16 + 16 * k0);
-        const long long f1 = (long long)(y0 - 1 + r1) * W + (x0 - 16 + 16 * k1);
-        const bool ok0 = f0 >= 0 && f0 < N;  // W % 16 == 0: a chunk is wholly inside or outside
-        const bool ok1 = c1 < nchunks && f1 >= 0 && f1 < N;
-        const long long g0 = ok0 ? f0 : 0, g1 = ok1 ? f1 : 0;
+        // second chunk of the pair: one stride further
+        int k1 = k0 + step_k, f1 = f0 + step_r * W + 16 * step_k, t1 = t0 + step_r * pitch + 16 * step_k;
+        if (k1 >= cpr) { k1 -= cpr; f1 += df_row; t1 += dt_row; }
+        const bool in1 = c + CS_THREADS < nchunks;
+        const bool ok0 = f0 >= 0 && f0 < Ni;  // W % 16 == 0: a chunk is wholly inside or outside
+        const bool ok1 = in1 && f1 >= 0 && f1 < Ni;
+        const int g0 = ok0 ? f0 : 0, g1 = ok1 ? f1 : 0;
         u32x4 v0 = ld16<IAK_NT_CHAIN_LD>(src + g0);
         u32x4 v1 = ld16<IAK_NT_CHAIN_LD>(src + g1);
         v0 = chain_apply16(v0, g0, d, t);
         v1 = chain_apply16(v1, g1, d, t);
         const u32x4 zero = {0, 0, 0, 0};
-        *reinterpret_cast<u32x4 *>(tile + r0 * pitch + 16 * k0) = ok0 ? v0 : zero;
-        if (c1 < nchunks) *reinterpret_cast<u32x4 *>(tile + r1 * pitch + 16 * k1) = ok1 ? v1 : zero;
+        *reinterpret_cast<u32x4 *>(tile + t0) = ok0 ? v0 : zero;
+        if (in1) *reinterpret_cast<u32x4 *>(tile + t1) = ok1 ? v1 : zero;
+        // first chunk of the next pair: two strides from this one
+        k0 = k1 + step_k; f0 = f1 + step_r * W + 16 * step_k; t0 = t1 + step_r * pitch + 16 * step_k;
+        if (k0 >= cpr) { k0 -= cpr; f0 += df_row; t0 += dt_row; }
     }
     __syncthreads();
 

@@ -255,7 +255,7 @@ long long iak_features_workspace_bytes(int W, int H, int B) {
     bytes += (long long)B * CHAIN_MAX * 256 * 2;  // mask table
     bytes += (long long)B * 4 * 2;                // edge counts, thresholds
     bytes = (bytes + 255) & ~255LL;
-    if (W % 16 != 0) bytes += 2 * (((long long)B * N + 255) & ~255LL) + (long long)B * 256 * 4;  // mask, edges, their histogram
+    if (W % 16 != 0 || N >= (1LL << 30)) bytes += 2 * (((long long)B * N + 255) & ~255LL) + (long long)B * 256 * 4;  // mask, edges, their histogram
     return bytes;
 }
 
@@ -281,7 +281,9 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
     hipLaunchKernelGGL(features_stats_kernel, dim3(B), dim3(256), 0, s, hist, (int)N, B, features, tables, counts,
                        thr);
     IAK_LAUNCH_CHECK();
-    if (W % 16 == 0 && aligned16(img) && stride % 16 == 0) {
+    if (W % 16 == 0 && N < (1LL << 30)) {
+        // the workspace for this shape holds no image buffers: the one-pass form is the only one
+        if (!aligned16(img) || stride % 16 != 0) return IAK_E_UNSUPPORTED;
         ChainDesc d;
         memset(&d, 0, sizeof d);
         d.n = 1;
