@@ -147,3 +147,13 @@ def test_knn_crossval_through_the_driver(tmp_path):
     assert f"Average accuracy was {np.float64(np.sum(folds.astype(np.float64)) / 10.0):f}" in lines
     last = [l for l in lines if l.startswith("Total time required for a tenfold cross validation knn with k of 3 on 203 instances with 7 features")]
     assert len(last) == 1 and f"achieved accuracy of {np.float32(acc * 100.0):0.4f}%, precision of: {prec:f}, and recall of {rec:f}" in last[0]
+
+
+def test_features_unaligned_batch_is_refused(ops):
+    from imageanalysis_amd.lib import IakError
+    W, H, B = 64, 32, 2
+    buf = torch.zeros(B * H * W + 8, dtype=torch.uint8, device="cuda")
+    x = buf[8:].view(B, H, W)          # 8 bytes off a 16-byte boundary
+    assert x.data_ptr() % 16 == 8
+    with pytest.raises(IakError):
+        ops.featureExtraction(x)
