@@ -194,8 +194,8 @@ int iak_gauss_table(const uint32_t *hist, int numPixels, int B, float mean, floa
     return 0;
 }
 
-int iak_rng_planes(uint32_t *x0, uint32_t *x1, long long N, unsigned long long seed, void *stream) {
-    if (!x0 || !x1 || N <= 0 || N > 0xffffffffLL) return IAK_E_ARG;
+int iak_rng_planes_from_state(uint32_t *x0, uint32_t *x1, long long N, const uint32_t *state6, void *stream) {
+    if (!x0 || !x1 || !state6 || N <= 0 || N > 0xffffffffLL) return IAK_E_ARG;
     hipStream_t s = as_stream(stream);
     // The jump matrices live in this code object's device memory, one copy per GPU.
     static std::mutex mu;
@@ -213,19 +213,22 @@ int iak_rng_planes(uint32_t *x0, uint32_t *x1, long long N, unsigned long long s
         }
     }
     XwSeed sd;
+    for (int i = 0; i < 5; i++) sd.v[i] = state6[i];
+    sd.d = state6[5];
+    hipLaunchKernelGGL(rng_planes_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, x0, x1, N, sd);
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
+int iak_rng_planes(uint32_t *x0, uint32_t *x1, long long N, unsigned long long seed, void *stream) {
+    // curand_init's seed scrambling as the public curand_kernel.h has it
     const uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
     const uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
     const uint32_t t0 = 1099087573u * s0;
     const uint32_t t1 = 2591861531u * s1;
-    sd.d = 6615241u + t1 + t0;
-    sd.v[0] = 123456789u + t0;
-    sd.v[1] = 362436069u ^ t0;
-    sd.v[2] = 521288629u + t1;
-    sd.v[3] = 88675123u ^ t1;
-    sd.v[4] = 5783321u + t0;
-    hipLaunchKernelGGL(rng_planes_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, x0, x1, N, sd);
-    IAK_LAUNCH_CHECK();
-    return 0;
+    const uint32_t st[6] = {123456789u + t0, 362436069u ^ t0, 521288629u + t1, 88675123u ^ t1, 5783321u + t0,
+                            6615241u + t1 + t0};
+    return iak_rng_planes_from_state(x0, x1, N, st, stream);
 }
 
 int iak_rv_plane(const uint32_t *x0, uint8_t *rv, long long N, void *stream) {

@@ -50,6 +50,7 @@ SIGNATURES = {
     "iak_mean_std": [_vp, _vp, _i, _i, _vp],
     "iak_msqe": [_vp, _vp, _vp, _vp, _ll, _i, _ll, _ll, _vp],
     "iak_rng_planes": [_vp, _vp, _ll, C.c_ulonglong, _vp],
+    "iak_rng_planes_from_state": [_vp, _vp, _ll, _vp, _vp],
     "iak_rv_plane": [_vp, _vp, _ll, _vp],
     "iak_sp_plane": [_vp, _vp, _vp, _ll, _i, _vp],
     "iak_salt_pepper": [_vp, _vp, _ll, _i, _ll, _ll, _vp, _vp],

@@ -113,6 +113,12 @@ int iak_msqe(const uint8_t *in, const uint8_t *out, const uint32_t *hist, uint32
  * two outputs the noise kernels ever consume, because they never store their state
  * back (imageAnalysis.cu:723,836).  x0/x1: DEVICE arrays of N words. */
 int iak_rng_planes(uint32_t *x0, uint32_t *x1, long long N, unsigned long long seed, void *stream);
+/* The same planes from an explicit start state (HOST array: x[0..4], then the Weyl counter d)
+ * instead of a seed: subsequence tid = 2^67 * tid steps from that state, two draws.
+ * iak_rng_planes is this with cuRAND's seed scrambling in front.  rocRAND's XORWOW is the same
+ * generator with other scrambling constants, so through this entry the jump, the step and the
+ * output function are checked against rocRAND bit for bit (tests/cpp/rocrand_check.hip). */
+int iak_rng_planes_from_state(uint32_t *x0, uint32_t *x1, long long N, const uint32_t *state6, void *stream);
 /* rv[t] = (int)(uniform(x0[t]) * 255.999999), the draw of imageAnalysis.cu:837. */
 int iak_rv_plane(const uint32_t *x0, uint8_t *rv, long long N, void *stream);
 /* sp[t] = 0 keep, 1 pepper (0), 2 salt (255) for a given level (imageAnalysis.cu:724-731). */

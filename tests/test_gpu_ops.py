@@ -362,3 +362,36 @@ def test_strided_batch_views(ops):
         got = host(ops.histogramEqualization(view))
         for b in range(3):
             assert np.array_equal(got[b], O.equalize(imgs[b]))
+
+
+@pytest.mark.parametrize("seed,n", [(1234, 768 * 568), (1234, 70000), (987654321012345, 5000), (0, 300)])
+def test_random_planes_match_rocrand_xorwow(ops, seed, n, tmp_path):
+    """A second implementation of the generator: rocRAND's XORWOW device API (shipped with ROCm)
+    called the way the reference calls cuRAND -- init(seed, subsequence = pixel index, offset 0),
+    then two draws.  rocRAND is the same generator as cuRAND's except for the constants that
+    scramble the seed into the start state, so the start state is computed here with rocRAND's
+    constants and handed to iak_rng_planes_from_state: the 2^67-step subsequence jump, the step
+    and the output function must then match rocRAND bit for bit."""
+    import ctypes as C
+    import os
+    import subprocess
+    from imageanalysis_amd import lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "imageanalysis_amd", "lib", "rocrand_check")
+    out = tmp_path / "draws.bin"
+    r = subprocess.run([exe, str(n), str(seed), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    want = np.fromfile(out, dtype=np.uint32).reshape(n, 2)
+    M = 0xffffffff
+    s0 = (seed & M) ^ 0x2c7f967f                      # rocrand_xorwow.h: xorwow_engine constructor
+    s1 = ((seed >> 32) & M) ^ 0xa03697cb
+    t0 = (1228688033 * s0) & M
+    t1 = (2073658381 * s1) & M
+    state = np.array([(123456789 + t0) & M, 362436069 ^ t0, (521288629 + t1) & M, 88675123 ^ t1, (5783321 + t0) & M,
+                      (6615241 + t1 + t0) & M], np.uint32)
+    x0 = torch.empty(n, dtype=torch.int32, device="cuda")
+    x1 = torch.empty(n, dtype=torch.int32, device="cuda")
+    L.check(L.load().iak_rng_planes_from_state(x0.data_ptr(), x1.data_ptr(), n, state.ctypes.data,
+                                               torch.cuda.current_stream().cuda_stream), "iak_rng_planes_from_state")
+    assert np.array_equal(x0.cpu().numpy().view(np.uint32), want[:, 0])
+    assert np.array_equal(x1.cpu().numpy().view(np.uint32), want[:, 1])
