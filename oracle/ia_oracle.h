@@ -12,7 +12,10 @@
  * thread per pixel" loop.  Where the reference is racy, reads out of bounds or
  * relies on undefined casts, the resolution used here is stated at the
  * function.  The known-answer vectors under tests/golden/ were produced by
- * this file and hand-checked against the source text.
+ * this file and hand-checked against the source text.  Two third-party
+ * pieces have a second source in this image and are checked against it by
+ * the tests: the XORWOW generator (jump, step, output) against rocRAND's
+ * device generator, and rand() against the C library.
  *
  * Float rules: compile with -ffp-contract=off; every float expression keeps
  * the reference's operand types and evaluation order.
