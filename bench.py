@@ -249,7 +249,7 @@ def main():
                        for n, ms, b, mm in groups],
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline belongs to the 1-GPU line only
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
             threads = max(1, min(threads, os.cpu_count() or 1, B))
             base, ref_out, n = cpu_baseline(rgb, threads, ops)
