@@ -27,9 +27,18 @@ inline std::string read(const std::string &path, Planar *out) {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return "cannot open";
     std::vector<uint8_t> d;
-    uint8_t buf[1 << 16];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long size = ftell(f);
+        if (size > 0) d.resize((size_t)size);
+        rewind(f);
+    }
+    if (!d.empty()) {
+        if (fread(d.data(), 1, d.size(), f) != d.size()) d.clear();
+    } else {  // not seekable: read to the end in pieces
+        uint8_t buf[1 << 16];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
+    }
     fclose(f);
     if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') return "not a BMP file";
     const uint32_t data_off = rd32(&d[10]);

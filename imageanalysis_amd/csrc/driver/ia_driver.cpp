@@ -28,6 +28,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <regex>
 #include <sstream>
 #include <string>
@@ -438,7 +439,7 @@ int run_batched(const Config &c, const vector<string> &files, vector<Op> &ops, i
         iak_pipeline *pipe = nullptr;
         uint8_t *d_rgb = nullptr, *d_out = nullptr;
         float *d_feat = nullptr;
-        vector<uint8_t> h_rgb, h_out;
+        std::unique_ptr<uint8_t[]> h_rgb, h_out;  // not value-initialised: hundreds of megabytes
         vector<float> h_feat;
         vector<string> pending;
     };
@@ -448,16 +449,16 @@ int run_batched(const Config &c, const vector<string> &files, vector<Op> &ops, i
         if (B == 0) return;
         const size_t N = (size_t)L.W * L.H;
         auto t0 = std::chrono::steady_clock::now();
-        DRV_CHECK(iak_memcpy_h2d(L.d_rgb, L.h_rgb.data(), 3 * N * (size_t)B, nullptr));
+        DRV_CHECK(iak_memcpy_h2d(L.d_rgb, L.h_rgb.get(), 3 * N * (size_t)B, nullptr));
         DRV_CHECK(iak_pipeline_run(L.pipe, L.d_rgb, L.d_out, B, nullptr, nullptr, nullptr));
         DRV_CHECK(iak_stream_sync(nullptr));
         pipeline_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         t0 = std::chrono::steady_clock::now();
         if (c.save_final) {
-            DRV_CHECK(iak_memcpy_d2h(L.h_out.data(), L.d_out, N * (size_t)B, nullptr));
+            DRV_CHECK(iak_memcpy_d2h(L.h_out.get(), L.d_out, N * (size_t)B, nullptr));
             for (int b = 0; b < B; b++) {
                 const string path = c.output_dir + "/" + L.pending[b];
-                const string err = bmp_io::write_gray(path, L.h_out.data() + N * (size_t)b, L.W, L.H);
+                const string err = bmp_io::write_gray(path, L.h_out.get() + N * (size_t)b, L.W, L.H);
                 if (!err.empty()) fprintf(stderr, "%s: %s\n", path.c_str(), err.c_str());
             }
         }
@@ -495,8 +496,8 @@ int run_batched(const Config &c, const vector<string> &files, vector<Op> &ops, i
             DRV_CHECK(iak_pipeline_set_input(L->pipe, input));
             DRV_CHECK(iak_malloc((void **)&L->d_rgb, 3 * N * (size_t)batch_size));
             DRV_CHECK(iak_malloc((void **)&L->d_out, N * (size_t)batch_size));
-            L->h_rgb.resize(3 * N * (size_t)batch_size);
-            L->h_out.resize(N * (size_t)batch_size);
+            L->h_rgb.reset(new uint8_t[3 * N * (size_t)batch_size]);
+            L->h_out.reset(new uint8_t[N * (size_t)batch_size]);
             if (has_features) {
                 DRV_CHECK(iak_malloc((void **)&L->d_feat, sizeof(float) * IAK_N_FEATURES * (size_t)batch_size));
                 DRV_CHECK(iak_pipeline_bind_features(L->pipe, L->d_feat));
@@ -504,7 +505,7 @@ int run_batched(const Config &c, const vector<string> &files, vector<Op> &ops, i
             }
         }
         const size_t N = (size_t)L->W * L->H;
-        memcpy(L->h_rgb.data() + 3 * N * L->pending.size(), img.rgb.data(), 3 * N);
+        memcpy(L->h_rgb.get() + 3 * N * L->pending.size(), img.rgb.data(), 3 * N);
         L->pending.push_back(file);
         load_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if ((int)L->pending.size() == batch_size) flush(*L);
@@ -592,6 +593,7 @@ int main(int argc, char *argv[]) {
         DRV_CHECK(iak_free(warm));
         srand(1);
     }
+    if ((size_t)batch_size > files.size()) batch_size = files.empty() ? 1 : (int)files.size();
     const int rc = (force_per_image || needs_per_image) ? run_per_image(c, files, ops) : run_batched(c, files, ops, batch_size);
     if (rc == 0 && c.knn) run_knn(c);  // after the batch, as the reference does (test/test.cu:587)
     return rc;
