@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--pointwise", action="store_true", help="fuse per-pixel runs only; stencils stay separate passes")
     ap.add_argument("--strips", action="store_true", help="also fuse runs of 3x3 stencils through LDS strips")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per GPU (executor streams)")
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="run the pipeline untimed for this long before the warm-up steps (clock ramp after the idle "
+                         "gap of input generation); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel events in the timed steps (no roofline)")
     args = ap.parse_args()
@@ -177,6 +180,14 @@ def main():
         if dist is not None:
             dist.all_reduce(hist_local, op=dist.ReduceOp.SUM)
 
+    if args.settle_ms > 0:
+        # The GPU has been idle or running small torch kernels while the inputs were made; its clocks take
+        # some tens of milliseconds of load to come back up.  Untimed, like the warm-up steps.
+        t_end = time.perf_counter() + args.settle_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     # per-kernel HIP events on a sample of the timed steps (every 8th, at least one): each timed
@@ -240,7 +251,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"batch of {B} {W}x{H} RGB cell-like images per GPU, {what}, device-resident",
-                       "images_per_gpu": B, "mode": "stagewise" if args.stagewise else ("fused-pointwise" if args.pointwise else ("fused-strips" if args.strips else "fused")), "lanes": args.lanes,
+                       "images_per_gpu": B, "settle_ms": args.settle_ms, "mode": "stagewise" if args.stagewise else ("fused-pointwise" if args.pointwise else ("fused-strips" if args.strips else "fused")), "lanes": args.lanes,
                        "parallelism": f"image-wise shards x{world}, dataset-histogram all-reduce per step"},
             "pipeline_frac_of_hbm_roofline": round(value * 1e6 * bytes_per_px / world / (HBM_PEAK_GBS * 1e9), 4),
             "groups": [{"name": n, "ms": round(ms, 4), "kernel_ms": round(mm, 4), "images": timed_images,
