@@ -47,6 +47,13 @@ def test_argument_errors_need_no_gpu():
     assert h.iak_gray(None, None, 4, 4, 1, 48, 16, 0, None) == L.IAK_E_ARG
     assert h.iak_median(None, None, 4, 4, 1, 16, 16, None, 3, 3, None) == L.IAK_E_ARG
     assert h.iak_pipeline_create(None, 4, 4, 1, None, 0, 1234, 1) == L.IAK_E_ARG
+    assert h.iak_features(None, 16, 16, 1, 256, None, None, None, None) == L.IAK_E_ARG
+    assert h.iak_features_workspace_bytes(0, 16, 1) == L.IAK_E_ARG
+    assert h.iak_features_workspace_bytes(768, 568, 500) < h.iak_features_workspace_bytes(769, 568, 500)
+    assert h.iak_kmeans2_map(None, 16, 1, None, None, None, None) == L.IAK_E_ARG
+    assert h.iak_knn_predict(None, None, 1, 1, 8, 3, None, None) == L.IAK_E_ARG
+    assert h.iak_channel_hist(None, None, None, 4, 4, 1, 48, 16, 3, None) == L.IAK_E_ARG
+    assert h.iak_rng_planes_from_state(None, None, 16, None, None) == L.IAK_E_ARG
 
 
 def test_cpp_api_library_exports_reference_functions():
@@ -60,7 +67,8 @@ def test_cpp_api_library_exports_reference_functions():
                "addGaussianNoise", "cleanupEdgeDetection", "setupEdgeDetection", "cleanupRandomness", "imageDilation",
                "imageErosion", "thresholdImage", "otsuThresholdImage", "kMeansThresholding(Image*, Image*, int)",
                "kMeansThresholding(Image*, Image*)", "extractSingleColorChannel", "setupRandomness",
-               "imageQuantization", "calcMSQE", "calculateMeanAndStdDev", "featureExtraction"):
+               "imageQuantization", "calcMSQE", "calculateMeanAndStdDev", "featureExtraction", "extractAllPixelsAsFeatures",
+               "knn(int, int, float*, float*, int, int*, int)", "knnTenfoldCrossVal"):
         assert fn in out, fn
 
 
