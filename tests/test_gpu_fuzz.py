@@ -93,3 +93,97 @@ def test_fuzz_pipeline(case):
         if has_features:
             assert np.array_equal(feats.cpu().numpy(), want_feats), (case, mode, names)
         p.close()
+
+
+def _placed(imgs, rs):
+    """The batch copied into a larger device buffer at a random byte offset with a random image
+    stride, as a [B, H, W] view: exercises the unaligned / strided paths of every entry point."""
+    B, H, W = imgs.shape
+    N = H * W
+    off = int(rs.choice([0, 0, 1, 3, 4, 8, 16, 20]))
+    stride = N + int(rs.choice([0, 0, 1, 5, 16, 64]))
+    buf = torch.zeros(off + stride * B + 64, dtype=torch.uint8, device="cuda")
+    view = torch.as_strided(buf[off:], (B, H, W), (stride, W, 1))
+    view.copy_(torch.from_numpy(imgs).cuda())
+    return view
+
+
+@pytest.mark.parametrize("case", range(120))
+def test_fuzz_entry_points(case):
+    from imageanalysis_amd import ops
+    rs = np.random.default_rng(5000 + case)
+    W = int(rs.choice([16, 32, 64, 128])) if rs.random() < 0.5 else int(rs.integers(1, 70))
+    H = int(rs.integers(1, 40))
+    B = int(rs.integers(1, 4))
+    kind = str(rs.choice(["C", "U", "K"]))
+    imgs = synth.gray_batch(kind, W, H, B, first_index=case)
+    if rs.random() < 0.3:
+        imgs[0, :, : W // 2] = 0
+    x = _placed(imgs, rs)
+    N = W * H
+    x0, x1 = O.xorwow_planes(N)
+    rng = ops.Randomness(N)
+
+    def check(got, fn, what):
+        got = got.cpu().numpy()
+        for b in range(B):
+            want = fn(imgs[b])
+            want = want[0] if isinstance(want, tuple) else want
+            assert np.array_equal(got[b], want), f"case {case} {what} {W}x{H} image {b} offset {x.data_ptr() % 16} stride {x.stride(0)}"
+
+    which = int(rs.integers(0, 12))
+    if which == 0:
+        check(ops.calculateHistogram(x), O.hist, "hist")
+        check(ops.histogramEqualization(x), O.equalize, "equalize")
+    elif which == 1:
+        t = int(rs.integers(-1, 257))
+        check(ops.thresholdImage(x, t), lambda g: O.threshold(g, t), "threshold")
+        check(ops.otsuThresholdImage(x), O.otsu, "otsu")
+    elif which == 2:
+        lv = [10, 20, 15, 30, 250, 77]
+        check(ops.imageQuantization(x, lv), lambda g: O.quantize(g, lv), "quantize")
+    elif which == 3:
+        level = int(rs.choice([0, 1, 50, 255]))
+        check(ops.saltAndPepperNoise(x, rng, level), lambda g: O.salt_pepper(g, x0, x1, level), "salt_pepper")
+    elif which == 4:
+        m, s = (-1.0, -1.0) if rs.random() < 0.5 else (float(rs.integers(0, 256)), float(rs.choice([0.0, 3.0, 50.0])))
+        check(ops.addGaussianNoise(x, rng, m, s), lambda g: O.gauss_noise(g, x0, m, s), "gauss")
+    elif which == 5:
+        k = int(rs.choice([3, 3, 5, 7]))
+        w = [float(v) for v in ((rs.random(k * k) - 0.2) * 2 / k).astype(np.float32)]
+        check(ops.linearFilter(x, w, k, k), lambda g: O.linear(g, w, k, k), "linear")
+        check(ops.averageFilter(x, w, k, k), lambda g: O.average(g, w, k, k), "average")
+    elif which == 6:
+        w = [float(v) for v in (rs.integers(0, 5, 9) / 8.0)]
+        check(ops.linearFilter(x, w, 3, 3), lambda g: O.linear(g, w, 3, 3), "linear dyadic")
+        wi = [float(v) for v in rs.integers(-2, 9, 9)]
+        check(ops.averageFilter(x, wi, 3, 3), lambda g: O.average(g, wi, 3, 3), "average integral")
+    elif which == 7:
+        kw, kh = int(rs.choice([3, 5, 7])), int(rs.choice([3, 5]))
+        w = [1] * (kw * kh)
+        check(ops.medianFilter(x, w, kw, kh), lambda g: O.median(g, w, kw, kh), "median")
+        w3 = [int(v) for v in rs.integers(0, 4, 9)]
+        w3[4] += 1
+        check(ops.medianFilter(x, w3, 3, 3), lambda g: O.median(g, w3, 3, 3), "weighted median")
+    elif which == 8:
+        check(ops.sobelFilter(x), O.sobel, "sobel")
+        check(ops.compassFilter(x), O.compass, "compass")
+    elif which == 9:
+        kw, kh = (3, 3) if rs.random() < 0.6 else (5, 3)
+        se = [int(v) for v in rs.integers(0, 2, kw * kh)]
+        check(ops.imageDilation(x, se, kw, kh), lambda g: O.dilate(g, se, kw, kh), "dilate")
+        check(ops.imageErosion(x, se, kw, kh), lambda g: O.erode(g, se, kw, kh), "erode")
+    elif which == 10:
+        cent = rs.integers(0, 257, (B, 2)).astype(np.int32)
+        got = ops.kMeansThresholding(x, torch.from_numpy(cent).cuda()).cpu().numpy()
+        for b in range(B):
+            assert np.array_equal(got[b], O.kmeans2(imgs[b], int(cent[b, 0]), int(cent[b, 1]))[0]), (case, b)
+    else:
+        if W % 16 == 0 and (x.data_ptr() % 16 or x.stride(0) % 16):
+            from imageanalysis_amd.lib import IakError
+            with pytest.raises(IakError):
+                ops.featureExtraction(x)
+        else:
+            got = ops.featureExtraction(x).cpu().numpy()
+            for b in range(B):
+                assert np.array_equal(got[b], O.features(imgs[b])), (case, b)
