@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=100.0,
                     help="run the pipeline untimed for this long before the warm-up steps (clock ramp after the idle "
                          "gap of input generation); 0 disables")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the all-reduce path even with one rank (self-test of the multi-GPU path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel events in the timed steps (no roofline)")
     args = ap.parse_args()
@@ -155,9 +157,28 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL writes its version banner (NCCL_DEBUG=VERSION) to stdout when the communicator comes
+        # up; stdout is reserved for the one JSON line, so file descriptor 1 points at stderr until
+        # the first collective has run.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if world == 1:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29517")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            probe = torch.zeros(1, dtype=torch.int64, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     iak_lib.load()
 
     global W, H
@@ -170,15 +191,30 @@ def main():
     if any(o["type"] == OP_FEATURES for o in ops):
         feats = torch.zeros((B, 7), dtype=torch.float32, device=dev)
         pipe.bind_features(feats)
-    hist_local = torch.zeros(256, dtype=torch.int64, device=dev)
+    # Two histogram buffers: the all-reduce of one batch's histogram runs on RCCL's stream while the
+    # next batch is already being processed into the other buffer.
+    hist_bufs = [torch.zeros(256, dtype=torch.int64, device=dev) for _ in range(2)]
+    pending = [None, None]
+    counter = [0]
 
     def step():
-        # the batch's grayscale histogram is added to hist_local by the run; across GPUs the
+        # the batch's grayscale histogram is added to the buffer by the run; across GPUs the
         # dataset-level histogram is the one exchange of the path (2 KiB, latency-bound)
-        hist_local.zero_()
-        pipe.run(rgb, out=out, hist_sum=hist_local)
+        k = counter[0] & 1
+        counter[0] += 1
+        if pending[k] is not None:
+            pending[k].wait()  # the reduction issued two steps ago: orders this stream after it, no host wait
+            pending[k] = None
+        hist_bufs[k].zero_()
+        pipe.run(rgb, out=out, hist_sum=hist_bufs[k])
         if dist is not None:
-            dist.all_reduce(hist_local, op=dist.ReduceOp.SUM)
+            pending[k] = dist.all_reduce(hist_bufs[k], op=dist.ReduceOp.SUM, async_op=True)
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     if args.settle_ms > 0:
         # The GPU has been idle or running small torch kernels while the inputs were made; its clocks take
@@ -195,12 +231,14 @@ def main():
     every = 1 if args.steps < 16 else 8
     nrec = 0 if args.no_events else min((args.steps + every - 1) // every, 256)
     pipe.set_timing(nrec, every=every)
+    drain()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
