@@ -254,7 +254,10 @@ typedef struct {
 typedef struct iak_pipeline iak_pipeline;
 /* Plans the pipeline for batches of up to maxB images of W x H and allocates everything a
  * run needs (two image buffers, histograms, tables, the random planes for `seed`).
- * This call allocates and synchronises; iak_pipeline_run does neither. */
+ * This call allocates and synchronises; iak_pipeline_run does neither.  A pipeline belongs to
+ * the device that is current when it is created (run it with that device current) and to one
+ * host thread at a time; runs on one pipeline share its buffers, so they must not overlap
+ * (enqueue them on one stream, or on streams ordered after one another). */
 int iak_pipeline_create(iak_pipeline **p, int W, int H, int maxB, const iak_op *ops, int nops,
                         unsigned long long seed, int mode);
 int iak_pipeline_destroy(iak_pipeline *p);
