@@ -296,35 +296,66 @@ struct Sobel8 {
     }
 };
 
-struct Compass8 : Unpacked8 {
+// Compass filter on 16-bit pairs (two pixels per instruction, rows unpacked as for Sobel8).
+// With the per-row horizontal terms
+//   D[j] = p[j+1] - p[j-1],   R[j] = p[j-1] + p[j] + p[j+1],   C[j] = p[j]
+// and V = R(down) - R(up), E = D(down) + D(up), F = E + D(mid), the four mask responses
+// (imageAnalysis.cu:599-602) are
+//   s0 = F + D(mid)   s1 = V + F   s2 = V + C(down) - C(up)   s3 = V - F
+// (east, south-east, south, south-west; expand the masks to check).  The running sum is carried
+// from mask to mask as in the reference (:607-618): sum = |s0|, then sum = |sum + s_k|, and the
+// result is the largest sum seen, low byte.  Everything stays within +-4080: int16 is exact.
+struct CompassRow {
+    s16x2 D[4];
+    s16x2 R[4];
+    s16x2 C[4];
+};
+
+struct Compass8 {
     static const bool kBorderZero = true;
-    __device__ __forceinline__ void compute(const PRow &u, const PRow &m, const PRow &d, uint32_t o[2]) const {
-        // the four masks (imageAnalysis.cu:599-602) from shared column terms
-        int s[10], t[10];
+    typedef CompassRow Row;
+    __device__ __forceinline__ static s16x2 pr(uint32_t hi_src, uint32_t lo_src, uint32_t sel) {
+        return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(hi_src, lo_src, sel));
+    }
+    __device__ __forceinline__ static s16x2 abs2(s16x2 x) {
+        const s16x2 zero = {0, 0};
+        return __builtin_elementwise_max(x, zero - x);
+    }
+    __device__ __forceinline__ void prepare(const Raw16 &q, int, int, int, int, CompassRow &r) const {
+        s16x2 o[5], e[4];  // O_k = (p[2k-1], p[2k]), E_k = (p[2k], p[2k+1]); selectors as in Sobel8
+        o[0] = pr(q.d[1], q.d[0], 0x0c040c03u);
+        o[1] = pr(q.d[1], q.d[1], 0x0c020c01u);
+        o[2] = pr(q.d[2], q.d[1], 0x0c040c03u);
+        o[3] = pr(q.d[2], q.d[2], 0x0c020c01u);
+        o[4] = pr(q.d[3], q.d[2], 0x0c040c03u);
+        e[0] = pr(q.d[1], q.d[1], 0x0c010c00u);
+        e[1] = pr(q.d[1], q.d[1], 0x0c030c02u);
+        e[2] = pr(q.d[2], q.d[2], 0x0c010c00u);
+        e[3] = pr(q.d[2], q.d[2], 0x0c030c02u);
 #pragma unroll
-        for (int i = 0; i < 10; i++) {
-            s[i] = (int)(u.p[i] + 2 * m.p[i] + d.p[i]);
-            t[i] = (int)d.p[i] - (int)u.p[i];
+        for (int k = 0; k < 4; k++) {
+            r.D[k] = o[k + 1] - o[k];
+            r.R[k] = o[k] + e[k] + o[k + 1];
+            r.C[k] = e[k];
         }
-        uint32_t res[8];
+    }
+    __device__ __forceinline__ void compute(const CompassRow &u, const CompassRow &m, const CompassRow &d, uint32_t o[2]) const {
+        s16x2 mx[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int a = u.p[j], b = u.p[j + 1], c = u.p[j + 2];
-            const int e = m.p[j], f = m.p[j + 2];
-            const int g = d.p[j], h = d.p[j + 1], i = d.p[j + 2];
-            const int s0 = s[j + 2] - s[j];
-            const int s2 = t[j] + 2 * t[j + 1] + t[j + 2];
-            const int s1 = 2 * (i - a) + (f - b) + (h - e);
-            const int s3 = 2 * (g - c) + (e - b) + (h - f);
-            // the running sum is carried from mask to mask (imageAnalysis.cu:607-618)
-            int sum = abs(s0);
-            int mx = sum;
-            sum = abs(sum + s1); mx = max(mx, sum);
-            sum = abs(sum + s2); mx = max(mx, sum);
-            sum = abs(sum + s3); mx = max(mx, sum);
-            res[j] = (uint32_t)mx;
+        for (int k = 0; k < 4; k++) {
+            const s16x2 V = d.R[k] - u.R[k];
+            const s16x2 F = d.D[k] + u.D[k] + m.D[k];
+            const s16x2 s0 = F + m.D[k], s1 = V + F, s2 = V + (d.C[k] - u.C[k]), s3 = V - F;
+            s16x2 sum = abs2(s0);
+            s16x2 best = sum;
+            sum = abs2(sum + s1); best = __builtin_elementwise_max(best, sum);
+            sum = abs2(sum + s2); best = __builtin_elementwise_max(best, sum);
+            sum = abs2(sum + s3); best = __builtin_elementwise_max(best, sum);
+            mx[k] = best;
         }
-        pack8(res, o);
+        // low byte of each 16-bit result, four pixels per word
+        o[0] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, mx[1]), __builtin_bit_cast(uint32_t, mx[0]), 0x06040200u);
+        o[1] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, mx[3]), __builtin_bit_cast(uint32_t, mx[2]), 0x06040200u);
     }
 };
 
