@@ -14,6 +14,7 @@
 #include "iak_device_fns.hpp"
 #include "iak_block.hpp"
 #include "iak_chain.hpp"
+#include "iak_hist.hpp"
 #include "iak_chain_stencil.hpp"
 #include "iak_strip.hpp"
 #include "iak_stencil_ops.hpp"
@@ -120,11 +121,17 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *__restr
     }
 }
 
-template <bool VEC>
+// HIST: also accumulates the histogram of the output (hist[b][256], zeroed by the launcher, bin 0
+// left empty), for the consumer behind this run.
+template <bool VEC, bool HIST = false>
 __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                           long long N, long long in_stride, long long out_stride,
-                                                          ChainDesc d, const uint16_t *__restrict__ tables) {
+                                                          ChainDesc d, const uint16_t *__restrict__ tables,
+                                                          uint32_t *__restrict__ hist = nullptr) {
     __shared__ ChainTables t;
+    __shared__ uint32_t sh[HIST ? 256 * HIST_COLS : 1];
+    const int hcol = threadIdx.x & (HIST_COLS - 1);
+    if (HIST) hist_zero(sh);
     const int b = blockIdx.y;
     chain_load_tables(t, d, tables + (long long)b * CHAIN_MAX * 256);
     const uint8_t *src = in + (long long)b * in_stride;
@@ -146,10 +153,23 @@ __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restr
             const u32x4 y1 = chain_apply16(v1, off1, d, t);
             st16<IAK_NT_CHAIN_ST>(dst + off0, y0);
             if (two) st16<IAK_NT_CHAIN_ST>(dst + off1, y1);
+            if (HIST) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) hist_add4(sh, y0[w], hcol);
+                if (two) {
+#pragma unroll
+                    for (int w = 0; w < 4; w++) hist_add4(sh, y1[w], hcol);
+                }
+            }
         }
         scalar_from = nchunks << 4;
     }
-    for (long long x = scalar_from + tid; x < N; x += nthreads) dst[x] = (uint8_t)chain_apply1(src[x], x, d, t);
+    for (long long x = scalar_from + tid; x < N; x += nthreads) {
+        const uint32_t y = chain_apply1(src[x], x, d, t) & 0xffu;
+        dst[x] = (uint8_t)y;
+        if (HIST) atomicAdd(&sh[y * HIST_COLS + hcol], 1u);
+    }
+    if (HIST) hist_flush(sh, hist + (long long)b * 256);
 }
 
 // dataset histogram: sum[v] += sum_b hist[b][v]; each workgroup folds 8 images
@@ -166,6 +186,11 @@ __global__ __launch_bounds__(256) void hist_accumulate_kernel(const uint32_t *__
 }
 
 }  // namespace iak
+
+namespace iak {
+int stencil3_with_hist(const iak_op &o, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+                       long long out_stride, uint32_t *hist, void *stream);  // iak_stencil.hip
+}
 
 using namespace iak;
 
@@ -189,6 +214,7 @@ struct Group {
     ChainDesc chain;      // G_CHAIN, G_CHAIN_OP, G_STRIP (n == 0: no per-pixel run in front)
     bool chain_needs_hist = false;
     StripDesc strip;      // G_STRIP
+    bool emit_hist = false;  // G_CHAIN, G_OP: the pass also leaves the histogram of its output
 };
 
 // operators the fused chain+stencil kernel can take over (the 8-pixel 3x3 family)
@@ -439,6 +465,14 @@ static int plan(iak_pipeline *p) {
         g.name = op_name(o.type);
         g.alg_bytes = op_alg_bytes(o.type) + (needs_hist(o) ? 1 : 0);
         if (g.kind == G_FEATURES) {  // the image and what is known about its histogram stay as they are
+            if (!hist_known) {  // the features start from the histogram of what they look at
+                Group gh;
+                gh.kind = G_HIST;
+                gh.name = "hist";
+                gh.alg_bytes = 1;
+                p->groups.push_back(gh);
+                hist_known = true;
+            }
             p->groups.push_back(g);
             i++;
             continue;
@@ -446,6 +480,22 @@ static int plan(iak_pipeline *p) {
         p->groups.push_back(g);
         hist_known = false;
         i++;
+    }
+    // A histogram pass right behind a per-pixel run or a 3x3 stencil is folded into that pass
+    // (the pixels are in registers there): the producer also leaves the histogram of its output.
+    if (p->mode != IAK_PIPE_STAGEWISE) {
+        for (size_t k = 1; k < p->groups.size(); k++) {
+            if (p->groups[k].kind != G_HIST) continue;
+            Group &prev = p->groups[k - 1];
+            const bool stencil_ok = prev.kind == G_OP && is_fusable_stencil(p->ops[prev.op_index].op) && p->W % 8 == 0 &&
+                                    (long long)p->W * p->H < (1LL << 30);
+            if (prev.kind != G_CHAIN && !stencil_ok) continue;
+            prev.emit_hist = true;
+            prev.alg_bytes += 1;
+            prev.name += "+hist";
+            p->groups.erase(p->groups.begin() + (long)k);
+            k--;
+        }
     }
     if ((int)p->groups.size() > IAK_PIPE_MAX_STAGES) return IAK_E_TOO_LARGE;
     return 0;
@@ -744,6 +794,21 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             bool vec = aligned16(cur) && aligned16(dst) && N % 16 == 0;
             for (int k = 0; k < g.chain.n; k++)
                 if (g.chain.st[k].plane && g.chain.st[k].type != C_KMEANS) vec = vec && aligned16(g.chain.st[k].plane);
+            if (g.emit_hist) {
+                // few, large workgroups: each pays a 32 KiB table and a 256-atomic merge.  The table
+                // prologue above has consumed the old histogram (stream order), so hist2 can be reused.
+                IAK_HIP(hipMemsetAsync(sl.hist2, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
+                dim3 grid(blocks_x(vec ? N / 32 : N, 256, B, 4096), B);
+                if (vec)
+                    hipLaunchKernelGGL((chain_apply_kernel<true, true>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd, sl.tables,
+                                       sl.hist2);
+                else
+                    hipLaunchKernelGGL((chain_apply_kernel<false, true>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd,
+                                       sl.tables, sl.hist2);
+                IAK_LAUNCH_CHECK();
+                cur_hist = sl.hist2;
+                break;
+            }
             dim3 grid(blocks_x(vec ? N / 32 : N, 256, B, 32768), B);
             if (vec)
                 hipLaunchKernelGGL((chain_apply_kernel<true>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd, sl.tables);
@@ -817,6 +882,15 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
                               p->feat_ws + (size_t)b0 * (size_t)p->feat_ws_per_image, s);
             break;
         case G_OP:
+            if (g.emit_hist) {
+                rc = stencil3_with_hist(p->ops[g.op_index].op, cur, dst, p->W, p->H, B, N, N, sl.hist2, s);
+                if (rc == IAK_E_UNSUPPORTED) {  // buffers not aligned for the 8-pixel path: two passes
+                    rc = run_single_op(p, sl, p->ops[g.op_index].op, cur, dst, B, nullptr, s);
+                    if (rc == 0) rc = iak_hist(dst, sl.hist2, N, B, N, s);
+                }
+                cur_hist = sl.hist2;
+                break;
+            }
             rc = run_single_op(p, sl, p->ops[g.op_index].op, cur, dst, B,
                                kmeans_of(p, p->ops[g.op_index].kmeans_index, b0), s);
             cur_hist = nullptr;

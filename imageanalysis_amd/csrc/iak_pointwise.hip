@@ -4,6 +4,7 @@
 // (blocks per image, B) with a grid-stride loop inside the image.
 #include "iak_common.hpp"
 #include "iak_device_fns.hpp"
+#include "iak_hist.hpp"
 
 namespace iak {
 
@@ -163,33 +164,6 @@ struct GaussFn {
 // are summed at the end and each non-empty bin is merged into the image's global
 // histogram with one atomic per workgroup.
 // ---------------------------------------------------------------------------------------
-#define HIST_COLS 32
-
-__device__ __forceinline__ void hist_zero(uint32_t *sh) {
-    for (int i = threadIdx.x; i < 256 * HIST_COLS; i += blockDim.x) sh[i] = 0;
-    __syncthreads();
-}
-
-__device__ __forceinline__ void hist_add4(uint32_t *sh, uint32_t w, int col) {
-    atomicAdd(&sh[(w & 0xff) * HIST_COLS + col], 1u);
-    atomicAdd(&sh[((w >> 8) & 0xff) * HIST_COLS + col], 1u);
-    atomicAdd(&sh[((w >> 16) & 0xff) * HIST_COLS + col], 1u);
-    atomicAdd(&sh[(w >> 24) * HIST_COLS + col], 1u);
-}
-
-// 256 lanes: lane v sums the 32 columns of bin v (rotated start: conflict-free) and merges.
-// Value 0 is never reported (imageAnalysis.cu:136).
-__device__ __forceinline__ void hist_flush(const uint32_t *sh, uint32_t *hist_image) {
-    __syncthreads();
-    int v = threadIdx.x;
-    if (v < 256) {
-        uint32_t s = 0;
-#pragma unroll 8
-        for (int i = 0; i < HIST_COLS; i++) s += sh[v * HIST_COLS + ((i + v) & (HIST_COLS - 1))];
-        if (v != 0 && s != 0) atomicAdd(&hist_image[v], s);
-    }
-}
-
 __device__ __forceinline__ uint32_t lum1(uint32_t r, uint32_t g, uint32_t b) {
     // imageAnalysis.cu:22, double literals, left-to-right, no contraction
     double y = (.21 * (double)r + .72 * (double)g) + .07 * (double)b;
@@ -313,15 +287,6 @@ __global__ __launch_bounds__(256) void msqe_kernel(const uint8_t *__restrict__ i
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&sums[b], part[0] + part[1] + part[2] + part[3]);
-}
-
-// A workgroup's 32 KiB table and its 256-atomic merge are amortised over the pixels it
-// streams: give each at least ~64K pixels, and keep the whole launch near 2-4K workgroups.
-static int hist_blocks_x(long long N, int B) {
-    long long max_by_work = (N + 65535) / 65536;
-    long long want = (2048 + B - 1) / B;
-    long long bx = want < max_by_work ? want : max_by_work;
-    return (int)(bx < 1 ? 1 : bx);
 }
 
 }  // namespace iak

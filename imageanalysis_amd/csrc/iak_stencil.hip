@@ -11,6 +11,7 @@
 //     themselves are in iak_stencil_ops.hpp);
 //   * a generic path (any width, any kW x kH up to IAK_MAX_TAPS), one pixel per lane.
 #include "iak_common.hpp"
+#include "iak_hist.hpp"
 #include "iak_stencil_ops.hpp"
 #include "iak_stencil_tiled.hpp"
 
@@ -202,9 +203,16 @@ __device__ __forceinline__ Raw16 load_raw(__amdgpu_buffer_rsrc_t rsrc, int voffs
 //   void prepare(const Raw16&, row, col0, W, H, Row&)
 //   void compute(const Row& up, const Row& mid, const Row& dn, uint32_t o[2])
 //   static const bool kBorderZero
-template <class Op, int RPL>
+// HIST: the histogram of the OUTPUT image is accumulated on the way (hist[b][256], zeroed by the
+// launcher; bin 0 left empty as calculateHistogram does), so that a consumer of that histogram
+// needs no pass of its own.
+template <class Op, int RPL, bool HIST = false>
 __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
-                                                       int H, long long in_stride, long long out_stride, Op op) {
+                                                       int H, long long in_stride, long long out_stride, Op op,
+                                                       uint32_t *__restrict__ hist = nullptr) {
+    __shared__ uint32_t sh[HIST ? 256 * HIST_COLS : 1];
+    if (HIST) hist_zero(sh);
+    const int hcol = threadIdx.x & (HIST_COLS - 1);
     const uint8_t *src = in + (long long)blockIdx.y * in_stride;
     uint8_t *dst = out + (long long)blockIdx.y * out_stride;
     const int N = W * H;
@@ -242,11 +250,16 @@ __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict
             }
             if (row < H) {
                 st8<IAK_NT_STENCIL_ST>(dst + (long long)row * W + col0, o[0], o[1]);
+                if (HIST) {
+                    hist_add4(sh, o[0], hcol);
+                    hist_add4(sh, o[1], hcol);
+                }
             }
             up = mid;
             mid = dn;
         }
     }
+    if (HIST) hist_flush(sh, hist + (long long)blockIdx.y * 256);
 }
 
 
@@ -263,8 +276,16 @@ static int launch8v(const uint8_t *in, uint8_t *out, int W, int H, int B, long l
 
 template <class Op>
 static int launch8(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
-                   const Op &op, void *stream) {
-    return launch8v<Op, 8>(in, out, W, H, B, in_stride, out_stride, op, stream);
+                   const Op &op, void *stream, uint32_t *hist = nullptr) {
+    if (!hist) return launch8v<Op, 8>(in, out, W, H, B, in_stride, out_stride, op, stream);
+    // with the histogram: few, large workgroups per image (each pays a 32 KiB table and a 256-atomic merge)
+    hipStream_t s = as_stream(stream);
+    IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
+    const long long items = (long long)(W >> 3) * ((H + 7) / 8);
+    dim3 grid(blocks_x(items, 256, B, 4096), B);
+    hipLaunchKernelGGL((stencil8_kernel<Op, 8, true>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, op, hist);
+    IAK_LAUNCH_CHECK();
+    return 0;
 }
 
 static int check_image_args(const uint8_t *in, const uint8_t *out, int W, int H, int B, long long in_stride,
@@ -277,6 +298,43 @@ static int check_image_args(const uint8_t *in, const uint8_t *out, int W, int H,
 }
 
 static dim3 generic_grid(int W, int H, int B) { return dim3(blocks_x((long long)W * H, 256, B, 16384), B); }
+
+// The 3x3 operations of the 8-pixel path with the output's histogram as a by-product, for the
+// executor (not part of the C ABI).  IAK_E_UNSUPPORTED when the operation or the buffers do not
+// qualify; the caller then runs the operation and a histogram pass separately.
+int stencil3_with_hist(const iak_op &o, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+                       long long out_stride, uint32_t *hist, void *stream) {
+    if (check_image_args(in, out, W, H, B, in_stride, out_stride) || !hist) return IAK_E_ARG;
+    if (!fast8_ok(in, out, W, H, in_stride, out_stride)) return IAK_E_UNSUPPORTED;
+    auto go = [&](const auto &op) { return launch8(in, out, W, H, B, in_stride, out_stride, op, stream, hist); };
+    switch (o.type) {
+    case IAK_OP_LINEAR:
+        if (o.kW != 3 || o.kH != 3) return IAK_E_UNSUPPORTED;
+        return with_linear3_op<false>(o.fkernel, go);
+    case IAK_OP_AVERAGE:
+        if (o.kW != 3 || o.kH != 3) return IAK_E_UNSUPPORTED;
+        return with_linear3_op<true>(o.fkernel, go);
+    case IAK_OP_MEDIAN:
+        if (o.kW != 3 || o.kH != 3) return IAK_E_UNSUPPORTED;
+        for (int i = 0; i < 9; i++)
+            if (o.ikernel[i] != 1) return IAK_E_UNSUPPORTED;
+        return go(Median8());
+    case IAK_OP_SOBEL: return go(Sobel8());
+    case IAK_OP_COMPASS: return go(Compass8());
+    case IAK_OP_ERODE: case IAK_OP_DILATE: {
+        if (o.kW != 3 || o.kH != 3) return IAK_E_UNSUPPORTED;
+        if (o.type == IAK_OP_ERODE) {
+            Erode8 op;
+            op.mask = se_mask3(o.ikernel);
+            return go(op);
+        }
+        Dilate8 op;
+        op.mask = se_mask3(o.ikernel);
+        return go(op);
+    }
+    default: return IAK_E_UNSUPPORTED;
+    }
+}
 
 }  // namespace iak
 

@@ -16,6 +16,13 @@ CASES = {
     "morph": [{"type": 12}, {"type": 10, "kW": 3, "kH": 3, "ikernel": ONES}, {"type": 10, "kW": 3, "kH": 3, "ikernel": CROSS}],
     "medsob": [{"type": 6, "kW": 3, "kH": 3, "ikernel": ONES}, {"type": 7}],
     "pa": bench.P_A,
+    "input": [  # test/configs/input.json
+        {"type": 2, "mean": -1.0, "stddev": -1.0}, {"type": 1}, {"type": 13, "ikernel": [10, 20, 15, 30, 250, 77], "iparam": 2},
+        {"type": 4, "kW": 3, "kH": 3, "fkernel": [1, 1, 1, 10, 1, 1, 1, 1, 1]},
+        {"type": 5, "kW": 3, "kH": 3, "fkernel": [1, 1, 1, 10, 1, 1, 1, 1, 1]}, {"type": 3, "iparam": 50},
+        {"type": 6, "kW": 3, "kH": 3, "ikernel": ONES}, {"type": 7}, {"type": 8}, {"type": 11, "iparam": 40},
+        {"type": 9, "kW": 3, "kH": 3, "ikernel": CROSS}, {"type": 10, "kW": 3, "kH": 3, "ikernel": CROSS}, {"type": 12},
+        {"type": 14}, {"type": 15}],
 }
 B = 500
 rgb = bench.make_cell_batch(B, torch.device("cuda"), 1)
@@ -23,6 +30,7 @@ out = torch.empty((B, bench.H, bench.W), dtype=torch.uint8, device="cuda")
 for name in sys.argv[1:]:
     for mode in [False, "pointwise", True, "strips"]:
         p = Pipeline(bench.W, bench.H, B, CASES[name], fused=mode)
+        p.bind_features(torch.zeros((B, 7), dtype=torch.float32, device="cuda"))
         for _ in range(3):
             p.run(rgb, out=out)
         p.set_timing(10)
@@ -32,5 +40,6 @@ for name in sys.argv[1:]:
         for sl in range(10):
             for n, ms, b, mm in p.timings(sl):
                 acc[n] = acc.get(n, 0) + ms / 10
+        acc = dict(sorted(acc.items(), key=lambda kv: -kv[1]))
         print(name, mode, " total %.1f us  " % (1e3 * sum(acc.values())), {k: round(v * 1e3, 1) for k, v in acc.items()})
         p.close()
