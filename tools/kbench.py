@@ -53,6 +53,7 @@ def main():
     box11 = np.full(121, 1.0 / 121, np.float32)
     ones25f = np.ones(25, np.float32)
     ones49 = np.ones(49, np.int32)
+    wmed = np.array([1, 2, 1, 2, 3, 2, 1, 2, 1], np.int32)
     g, o = gray.data_ptr(), out.data_ptr()
     cases = {
         "copy(torch)": (lambda: out.copy_(gray), 2),
@@ -71,6 +72,9 @@ def main():
         "compass": (lambda: lib.iak_compass(g, o, W, H, B, N, N, st()), 2),
         "erode3": (lambda: lib.iak_erode(g, o, W, H, B, N, N, cross.ctypes.data, 3, 3, st()), 2),
         "dilate3": (lambda: lib.iak_dilate(g, o, W, H, B, N, N, cross.ctypes.data, 3, 3, st()), 2),
+        "median3_weighted": (lambda: lib.iak_median(g, o, W, H, B, N, N, wmed.ctypes.data, 3, 3, st()), 2),
+        "erode5": (lambda: lib.iak_erode(g, o, W, H, B, N, N, ones49.ctypes.data, 5, 5, st()), 2),
+        "linear5": (lambda: lib.iak_linear(g, o, W, H, B, N, N, ones25f.ctypes.data, 5, 5, 0, st()), 2),
         "linear11_box": (lambda: lib.iak_linear(g, o, W, H, B, N, N, box11.ctypes.data, 11, 11, 0, st()), 2),
         "average5": (lambda: lib.iak_linear(g, o, W, H, B, N, N, ones25f.ctypes.data, 5, 5, 1, st()), 2),
         "median7": (lambda: lib.iak_median(g, o, W, H, B, N, N, ones49.ctypes.data, 7, 7, st()), 2),
