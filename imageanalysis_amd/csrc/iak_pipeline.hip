@@ -70,15 +70,19 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *__restr
             // running sum strictly in bin order
             pdf[v] = (float)(int)hv / (float)numPixels;
             __syncthreads();
+            // the running sum goes to a second array: with no store into pdf[] the 256 LDS reads are
+            // independent of one another and pipeline, leaving only the chain of additions serial
+            float *cdf_out = reinterpret_cast<float *>(bs.ibuf);
             if (v == 0) {
                 float cdf = 0.0f;
+#pragma unroll 16
                 for (int i = 0; i < 256; i++) {
                     cdf = (i > 0) ? (pdf[i] + cdf) : pdf[i];
-                    pdf[i] = cdf;
+                    cdf_out[i] = cdf;
                 }
             }
             __syncthreads();
-            lut = (uint32_t)(int)(pdf[v] * 255) & 0xffu;
+            lut = (uint32_t)(int)(cdf_out[v] * 255) & 0xffu;
         } else if (st.type == C_OTSU) {
             block_otsu(hv, numPixels, bs);
             lut = (v > bs.thr) ? 255u : 0u;

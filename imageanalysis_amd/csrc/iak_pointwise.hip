@@ -304,10 +304,11 @@ static int gray_launch(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W,
     dim3 block(GRAY_THREADS);
     if (hist) {
         IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
-        // every workgroup pays a 32 KiB clear and a 256-atomic merge: at least 128K pixels each,
-        // and about 2-4 workgroups per CU over the whole launch
+        // every workgroup pays a 32 KiB clear and a 256-atomic merge: about 1024 workgroups over the
+        // whole launch (2-4 per CU), but never less than 16K pixels each -- a single image still gets
+        // a few dozen workgroups instead of streaming through three or four
         long long bx = (1024 + B - 1) / B;
-        const long long by_work = (N + 131071) / 131072;
+        const long long by_work = (N + 16383) / 16384;
         if (bx > by_work) bx = by_work;
         if (bx < 1) bx = 1;
         dim3 grid((unsigned)bx, B);
