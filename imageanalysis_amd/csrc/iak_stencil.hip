@@ -388,6 +388,16 @@ int iak_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long i
     if (kernSum <= 0 || kernSum > 0x7fffffff) return IAK_E_UNSUPPORTED;
     if (kW == 3 && kH == 3 && ones && fast8_ok(in, out, W, H, in_stride, out_stride))
         return launch8(in, out, W, H, B, in_stride, out_stride, Median8(), stream);
+    if (kW == 3 && kH == 3 && fast8_ok(in, out, W, H, in_stride, out_stride)) {
+        bool small = true;
+        for (int i = 0; i < 9; i++) small = small && weights[i] <= 255;
+        if (small) {
+            WMedian8 op;
+            for (int i = 0; i < 9; i++) op.w[i] = (uint32_t)weights[i];
+            op.rank = (uint32_t)(kernSum / 2);
+            return launch8(in, out, W, H, B, in_stride, out_stride, op, stream);
+        }
+    }
     if (ones) {
         rc = launch_huang_median(in, out, W, H, B, in_stride, out_stride, kW, kH, as_stream(stream));
         if (rc != IAK_E_UNSUPPORTED) return rc;

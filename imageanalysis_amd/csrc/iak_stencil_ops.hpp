@@ -381,6 +381,47 @@ struct Median8 : Unpacked8 {
     }
 };
 
+// Weighted 3x3 median, every weight in [0, 255]: the nine keys (pixel << 8 | weight) are sorted
+// with a 25-comparator network (min/max pairs; ties between equal pixels do not matter), the
+// weights are summed along the sorted order, and the answer is the pixel of the first key at
+// which the running weight exceeds kernSum/2 -- element kernSum/2 of the reference's replicated,
+// sorted window (imageAnalysis.cu:653-677).
+struct WMedian8 : Unpacked8 {
+    static const bool kBorderZero = true;
+    uint32_t w[9];
+    uint32_t rank;  // kernSum / 2
+    __device__ __forceinline__ static void ce(uint32_t &a, uint32_t &b) {
+        const uint32_t lo = min(a, b), hi = max(a, b);
+        a = lo;
+        b = hi;
+    }
+    __device__ __forceinline__ void compute(const PRow &u, const PRow &m, const PRow &d, uint32_t o[2]) const {
+        uint32_t res[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t k[9] = {(u.p[j] << 8) | w[0], (u.p[j + 1] << 8) | w[1], (u.p[j + 2] << 8) | w[2],
+                             (m.p[j] << 8) | w[3], (m.p[j + 1] << 8) | w[4], (m.p[j + 2] << 8) | w[5],
+                             (d.p[j] << 8) | w[6], (d.p[j + 1] << 8) | w[7], (d.p[j + 2] << 8) | w[8]};
+            ce(k[0], k[3]); ce(k[1], k[7]); ce(k[2], k[5]); ce(k[4], k[8]);
+            ce(k[0], k[7]); ce(k[2], k[4]); ce(k[3], k[8]); ce(k[5], k[6]);
+            ce(k[0], k[2]); ce(k[1], k[3]); ce(k[4], k[5]); ce(k[7], k[8]);
+            ce(k[1], k[4]); ce(k[3], k[6]); ce(k[5], k[7]);
+            ce(k[0], k[1]); ce(k[2], k[4]); ce(k[3], k[5]); ce(k[6], k[8]);
+            ce(k[2], k[3]); ce(k[4], k[5]); ce(k[6], k[7]);
+            ce(k[1], k[2]); ce(k[3], k[4]); ce(k[5], k[6]);
+            uint32_t c[8];
+            c[0] = k[0] & 0xffu;
+#pragma unroll
+            for (int i = 1; i < 8; i++) c[i] = c[i - 1] + (k[i] & 0xffu);
+            uint32_t key = k[8];  // the whole weight is always enough
+#pragma unroll
+            for (int i = 7; i >= 0; i--) key = c[i] > rank ? k[i] : key;
+            res[j] = key >> 8;
+        }
+        pack8(res, o);
+    }
+};
+
 // morphology on bit masks: bit i of a row mask = pixel col0-1+i (i in [0,10)) is non-zero / is a source
 struct MRow8 {
     uint32_t bits;

@@ -395,3 +395,14 @@ def test_random_planes_match_rocrand_xorwow(ops, seed, n, tmp_path):
                                                torch.cuda.current_stream().cuda_stream), "iak_rng_planes_from_state")
     assert np.array_equal(x0.cpu().numpy().view(np.uint32), want[:, 0])
     assert np.array_equal(x1.cpu().numpy().view(np.uint32), want[:, 1])
+
+
+@pytest.mark.parametrize("weights", [
+    [1, 2, 1, 2, 3, 2, 1, 2, 1], [0, 1, 0, 1, 1, 1, 0, 1, 0], [0, 0, 0, 0, 1, 0, 0, 0, 0], [255] * 9,
+    [255, 0, 7, 1, 1, 1, 30, 2, 0], [1, 1, 1, 1, 1, 1, 1, 1, 2], [256, 1, 1, 1, 1, 1, 1, 1, 1], [5, 0, 0, 0, 0, 0, 0, 0, 5]])
+@pytest.mark.parametrize("W,H,kind", [(64, 48, "U"), (37, 23, "U"), (768, 24, "C")])
+def test_median3_weighted(ops, weights, W, H, kind):
+    """Weighted 3x3 medians: the sorting-network path (weights up to 255, zeros included) and the
+    bisection path behind it (a weight of 256, widths that are not a multiple of 8)."""
+    imgs = batch(kind, W, H, 2)
+    each(lambda x: ops.medianFilter(x, weights, 3, 3), lambda x: O.median(x, weights, 3, 3), imgs)
