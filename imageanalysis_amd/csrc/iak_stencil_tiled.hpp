@@ -4,6 +4,7 @@
 // kernels they take over from.
 #pragma once
 #include "iak_common.hpp"
+#include "iak_stencil_ops.hpp"
 
 namespace iak {
 
@@ -138,6 +139,119 @@ static int launch_tiled_linear(const uint8_t *in, uint8_t *out, int W, int H, in
     default: return IAK_E_UNSUPPORTED;
     }
 #undef TL_CASE
+}
+
+// ---------------------------------------------------------------------------------------
+// Erosion / dilation with structuring elements above 3x3 (odd window up to 25x25): the same
+// 64 x 32 output tile as the linear filter, on bit masks.  A lane owns 8 adjacent outputs of a
+// row; for each row of the structuring element it turns the 8+kW-1 staged bytes into a mask of
+// non-zero pixels and shifts it once per non-zero element: one AND (erosion) or OR (dilation)
+// covers all 8 outputs.
+//   erosion (imageAnalysis.cu:421-451): out = pixel if every element's tap is non-zero, else 0;
+//     border pixels 0.  The tile holds the pixels themselves.
+//   dilation (imageAnalysis.cu:381-404, a scatter from every non-border foreground pixel, the
+//     write race resolved as "255 wins"): out = 255 iff some element reaches the pixel from such
+//     a source, i.e. a gather through the mirrored element.  The tile holds 1 where the pixel is
+//     a source (foreground and not on ITS border, judged at its true row / column on the flat
+//     view), else 0.
+// ---------------------------------------------------------------------------------------
+struct SeRows {
+    uint32_t m[25];  // bit j of m[r]: element (r, j) is set (dilation: already mirrored)
+};
+
+template <bool ERODE>
+__global__ __launch_bounds__(256) void tiled_morph_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
+                                                          int H, long long in_stride, long long out_stride, int kW, int kH,
+                                                          int tiles_x, SeRows se) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    const int pitch = ((TL_TW + kW - 1 + 3) / 4) * 4 + 4;
+    const long long N = (long long)W * H;
+    const uint8_t *src = in + (long long)blockIdx.y * in_stride;
+    uint8_t *dst = out + (long long)blockIdx.y * out_stride;
+    const int a = (kH - 1) / 2, s = (kW - 1) / 2;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * TL_TW, y0 = ty * TL_TH;
+    const int rows = TL_TH + kH - 1, cols = TL_TW + kW - 1;
+    for (int e = threadIdx.x; e < rows * pitch; e += 256) {
+        const int r = e / pitch, c = e - r * pitch;
+        uint32_t v = 0;
+        if (c < cols) {
+            const long long idx = (long long)(y0 - a + r) * W + (x0 - s + c);
+            v = tap_at(src, N, idx);
+            if (!ERODE) {
+                const int urow = (int)(idx / W), ucol = (int)(idx - (long long)urow * W);  // idx < 0 gives v == 0 already
+                v = (v > 0 && !is_border(urow, ucol, W, H, a, s)) ? 1u : 0u;
+            }
+        }
+        tile[e] = (uint8_t)v;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 7, ly = threadIdx.x >> 3;
+    const int row = y0 + ly, col0 = x0 + lx * 8;
+    if (row >= H || col0 >= W) return;
+    const int nw = (8 + kW - 1 + 3) >> 2;  // dwords that cover the lane's 8+kW-1 pixels
+    uint32_t acc = ERODE ? 0xffu : 0u;
+    for (int r = 0; r < kH; r++) {
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(tile + (ly + r) * pitch + lx * 8);
+        uint32_t bits = 0;
+        for (int w = 0; w < nw; w++) bits |= nonzero4(rp[w]) << (4 * w);
+        uint32_t m = se.m[r];
+        for (int j = 0; m != 0; j++, m >>= 1)
+            if (m & 1u) acc = ERODE ? (acc & (bits >> j)) : (acc | (bits >> j));
+    }
+    acc &= 0xffu;
+    uint32_t o[2];
+    if (ERODE) {
+        const uint8_t *cp = tile + (ly + a) * pitch + lx * 8 + s;
+        uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            c0 |= (uint32_t)cp[i] << (8 * i);
+            c1 |= (uint32_t)cp[4 + i] << (8 * i);
+        }
+        o[0] = c0 & spread4(acc & 0xfu);
+        o[1] = c1 & spread4(acc >> 4);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (is_border(row, col0 + i, W, H, a, s)) o[i >> 2] &= ~(0xffu << (8 * (i & 3)));
+    } else {
+        o[0] = spread4(acc & 0xfu);
+        o[1] = spread4(acc >> 4);
+    }
+    uint8_t *q = dst + (long long)row * W + col0;
+    if (col0 + 8 <= W && ((reinterpret_cast<uintptr_t>(q) & 7u) == 0)) {
+        st8<true>(q, o[0], o[1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (col0 + i < W) q[i] = (uint8_t)(o[i >> 2] >> (8 * (i & 3)));
+    }
+}
+
+// se: the (2a+1) x (2s+1) elements actually visited, row-major.  IAK_E_UNSUPPORTED when this
+// path does not apply.
+static int launch_tiled_morph(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+                              long long out_stride, const int *se, int kWe, int kHe, bool erode, hipStream_t s) {
+    if (kWe > 25 || kHe > 25 || (long long)W * H >= (1LL << 31)) return IAK_E_UNSUPPORTED;
+    SeRows rows;
+    for (int r = 0; r < 25; r++) rows.m[r] = 0;
+    for (int r = 0; r < kHe; r++)
+        for (int j = 0; j < kWe; j++) {
+            const int n = erode ? r * kWe + j : (kHe - 1 - r) * kWe + (kWe - 1 - j);  // dilation gathers through the mirror image
+            if (se[n] != 0) rows.m[r] |= 1u << j;
+        }
+    const int tiles_x = (W + TL_TW - 1) / TL_TW, tiles_y = (H + TL_TH - 1) / TL_TH;
+    const dim3 grid((unsigned)(tiles_x * tiles_y), B);
+    const int pitch = ((TL_TW + kWe - 1 + 3) / 4) * 4 + 4;
+    const size_t lds = (size_t)(TL_TH + kHe - 1) * pitch + 16;
+    if (erode)
+        hipLaunchKernelGGL((tiled_morph_kernel<true>), grid, dim3(256), lds, s, in, out, W, H, in_stride, out_stride, kWe, kHe,
+                           tiles_x, rows);
+    else
+        hipLaunchKernelGGL((tiled_morph_kernel<false>), grid, dim3(256), lds, s, in, out, W, H, in_stride, out_stride, kWe, kHe,
+                           tiles_x, rows);
+    IAK_LAUNCH_CHECK();
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------

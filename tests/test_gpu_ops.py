@@ -331,11 +331,16 @@ SES = {
     "bar": (5, 1, [1, 0, 1, 1, 0]),
     "col": (1, 3, [1, 1, 1]),
     "even": (2, 2, [1, 1, 1, 1]),
+    "even43": (4, 3, [1, 0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 0]),
+    "rand7x3": (7, 3, [1, 0, 0, 1, 0, 1, 1, 0, 1, 0, 0, 0, 1, 0, 1, 0, 1, 1, 0, 0, 1]),
+    "sparse9": (9, 9, [1 if (i * 7) % 11 == 0 else 0 for i in range(81)]),
+    "ones25": (25, 25, [1] * 625),
+    "corners25": (25, 25, [1 if i in (0, 24, 600, 624, 312) else 0 for i in range(625)]),
 }
 
 
 @pytest.mark.parametrize("se", list(SES))
-@pytest.mark.parametrize("W,H", SIZES)
+@pytest.mark.parametrize("W,H", SIZES + [(200, 70), (131, 45)])
 def test_morphology(ops, se, W, H):
     kW, kH, v = SES[se]
     rs = np.random.default_rng(5)
