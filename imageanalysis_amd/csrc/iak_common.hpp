@@ -87,6 +87,16 @@ __device__ __forceinline__ void st8(uint8_t *p, uint32_t lo, uint32_t hi) {
     else *reinterpret_cast<u32x2 *>(p) = v;
 }
 
+// 8 bytes to an address of any alignment (one store instruction: the device handles unaligned
+// vector memory accesses)
+struct __attribute__((packed, aligned(1))) u32x2_unaligned { uint32_t lo, hi; };
+__device__ __forceinline__ void st8_unaligned(uint8_t *p, uint32_t lo, uint32_t hi) {
+    u32x2_unaligned v;
+    v.lo = lo;
+    v.hi = hi;
+    *reinterpret_cast<u32x2_unaligned *>(p) = v;
+}
+
 // float -> unsigned char where the reference leaves the cast undefined: truncate
 // toward zero to int, keep the low byte; NaN gives 0.
 __device__ __forceinline__ uint32_t f2u8(float v) {

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void generic_edge_kernel(const uint8_t *__rest
 }
 
 // =======================================================================================
-// 3x3 path, W % 8 == 0: 8 pixels per lane, one 16-byte buffer load per row
+// 3x3 path: 8 pixels per lane, one 16-byte buffer load per row
 // =======================================================================================
 // A lane owns the 8-pixel chunk [col0, col0+8) of a strip of rows.  For every input row it
 // issues ONE buffer_load_dwordx4 at flat offset row*W + col0 - 4: bytes col0-4 .. col0+11,
@@ -197,6 +197,22 @@ __device__ __forceinline__ Raw16 load_raw(__amdgpu_buffer_rsrc_t rsrc, int voffs
     return r;
 }
 
+// The same 16 bytes for a flat offset of any alignment.  The range check is per dword, so a
+// load that straddles either end of the image would lose the dword holding the first or the
+// last one to three pixels: those few loads are redone byte by byte.
+__device__ __forceinline__ Raw16 load_raw_any(__amdgpu_buffer_rsrc_t rsrc, const uint8_t *src, int N, int voffset) {
+    Raw16 r = load_raw(rsrc, voffset);
+    if ((voffset < 0 && voffset > -16) || (voffset < N && voffset + 16 > N)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const long long o = (long long)voffset + 4 * i;
+            r.d[i] = tap_at(src, N, o) | (tap_at(src, N, o + 1) << 8) | (tap_at(src, N, o + 2) << 16) |
+                     (tap_at(src, N, o + 3) << 24);
+        }
+    }
+    return r;
+}
+
 
 // Op interface (8-pixel form):
 //   typedef ... Row;
@@ -206,7 +222,11 @@ __device__ __forceinline__ Raw16 load_raw(__amdgpu_buffer_rsrc_t rsrc, int voffs
 // HIST: the histogram of the OUTPUT image is accumulated on the way (hist[b][256], zeroed by the
 // launcher; bin 0 left empty as calculateHistogram does), so that a consumer of that histogram
 // needs no pass of its own.
-template <class Op, int RPL, bool HIST = false>
+// ANYW: any width from 8 up and any alignment of the images.  Rows then start at arbitrary byte
+// offsets (unaligned 16-byte loads, unaligned 8-byte stores) and the last chunk of a row may be
+// partial: its pixels past the row's end are the next row's first ones, which is what the
+// reference's flat tap indices read there, and only its first W - col0 outputs are stored.
+template <class Op, int RPL, bool HIST = false, bool ANYW = false>
 __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
                                                        int H, long long in_stride, long long out_stride, Op op,
                                                        uint32_t *__restrict__ hist = nullptr) {
@@ -217,7 +237,7 @@ __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict
     uint8_t *dst = out + (long long)blockIdx.y * out_stride;
     const int N = W * H;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
-    const int chunks = W >> 3;
+    const int chunks = ANYW ? (W + 7) >> 3 : W >> 3;
     const int strips = (H + RPL - 1) / RPL;
     const int items = chunks * strips;
     for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < items; it += gridDim.x * blockDim.x) {
@@ -227,14 +247,20 @@ __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict
         const int y0 = strip * RPL;
         const int voff = (y0 - 1) * W + col0 - 4;
         Raw16 raw[RPL + 2];
+        if (ANYW) {
 #pragma unroll
-        for (int r = 0; r < RPL + 2; r++) raw[r] = load_raw(rsrc, voff + r * W);
-        if (y0 == 0 && col0 == 0) {
-            // the very first chunk of the image: offset -4 is out of range as a whole on some
-            // range-check implementations, so fetch from 0 and shift the dwords up by one
-            Raw16 f = load_raw(rsrc, 0);
-            raw[1].d[0] = 0; raw[1].d[1] = f.d[0]; raw[1].d[2] = f.d[1]; raw[1].d[3] = f.d[2];
+            for (int r = 0; r < RPL + 2; r++) raw[r] = load_raw_any(rsrc, src, N, voff + r * W);
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPL + 2; r++) raw[r] = load_raw(rsrc, voff + r * W);
+            if (y0 == 0 && col0 == 0) {
+                // the very first chunk of the image: offset -4 is out of range as a whole on some
+                // range-check implementations, so fetch from 0 and shift the dwords up by one
+                Raw16 f = load_raw(rsrc, 0);
+                raw[1].d[0] = 0; raw[1].d[1] = f.d[0]; raw[1].d[2] = f.d[1]; raw[1].d[3] = f.d[2];
+            }
         }
+        const int valid = ANYW ? W - col0 : 8;  // outputs of this chunk that exist
         typename Op::Row up, mid, dn;
         op.prepare(raw[0], y0 - 1, col0, W, H, up);
         op.prepare(raw[1], y0, col0, W, H, mid);
@@ -249,7 +275,19 @@ __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict
                 if (col0 == 0) o[0] &= 0xffffff00u;  // col < 1; col > W-1 cannot happen
             }
             if (row < H) {
-                st8<IAK_NT_STENCIL_ST>(dst + (long long)row * W + col0, o[0], o[1]);
+                uint8_t *q = dst + (long long)row * W + col0;
+                if (!ANYW) {
+                    st8<IAK_NT_STENCIL_ST>(q, o[0], o[1]);
+                } else if (valid >= 8) {
+                    st8_unaligned(q, o[0], o[1]);
+                } else {
+                    const uint64_t keep = (1ull << (8 * valid)) - 1;  // valid in [1, 7]
+                    o[0] &= (uint32_t)keep;
+                    o[1] &= (uint32_t)(keep >> 32);
+#pragma unroll
+                    for (int i = 0; i < 7; i++)
+                        if (i < valid) q[i] = (uint8_t)(o[i >> 2] >> (8 * (i & 3)));
+                }
                 if (HIST) {
                     hist_add4(sh, o[0], hcol);
                     hist_add4(sh, o[1], hcol);
@@ -263,27 +301,30 @@ __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict
 }
 
 
-template <class Op, int RPL>
-static int launch8v(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
-                    const Op &op, void *stream) {
-    const long long items = (long long)(W >> 3) * ((H + RPL - 1) / RPL);
-    dim3 grid(blocks_x(items, 256, B, 1 << 20), B);
-    hipLaunchKernelGGL((stencil8_kernel<Op, RPL>), grid, dim3(256), 0, as_stream(stream), in, out, W, H, in_stride,
-                       out_stride, op);
-    IAK_LAUNCH_CHECK();
-    return 0;
+static bool aligned8_ok(const uint8_t *in, const uint8_t *out, int W, long long in_stride, long long out_stride) {
+    return (W % 8 == 0) && (reinterpret_cast<uintptr_t>(in) % 4 == 0) && (reinterpret_cast<uintptr_t>(out) % 8 == 0) &&
+           in_stride % 4 == 0 && out_stride % 8 == 0;
 }
 
+// hist: the output's histogram on the way (few, large workgroups per image: each pays a 32 KiB
+// table and a 256-atomic merge)
 template <class Op>
 static int launch8(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
                    const Op &op, void *stream, uint32_t *hist = nullptr) {
-    if (!hist) return launch8v<Op, 8>(in, out, W, H, B, in_stride, out_stride, op, stream);
-    // with the histogram: few, large workgroups per image (each pays a 32 KiB table and a 256-atomic merge)
     hipStream_t s = as_stream(stream);
-    IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
-    const long long items = (long long)(W >> 3) * ((H + 7) / 8);
-    dim3 grid(blocks_x(items, 256, B, 4096), B);
-    hipLaunchKernelGGL((stencil8_kernel<Op, 8, true>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, op, hist);
+    const bool anyw = !aligned8_ok(in, out, W, in_stride, out_stride);
+    const long long items = (long long)((W + 7) >> 3) * ((H + 7) / 8);
+    if (hist) IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
+    const dim3 grid(blocks_x(items, 256, B, hist ? 4096 : 1 << 20), B);
+#define IAK_LAUNCH8(HIST, ANYW)                                                                                       \
+    hipLaunchKernelGGL((stencil8_kernel<Op, 8, HIST, ANYW>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, \
+                       op, hist)
+    if (hist) {
+        if (anyw) IAK_LAUNCH8(true, true); else IAK_LAUNCH8(true, false);
+    } else {
+        if (anyw) IAK_LAUNCH8(false, true); else IAK_LAUNCH8(false, false);
+    }
+#undef IAK_LAUNCH8
     IAK_LAUNCH_CHECK();
     return 0;
 }

@@ -472,7 +472,8 @@ struct Dilate8 {
             b &= ~2u;                   // column 0
             if (row - 1 < 1) b &= ~1u;  // left halo = (row-1, W-1)
         }
-        if (col0 + 8 >= W) b &= ~(1u << 9);  // right halo = (row+1, 0): column 0
+        const int e = W - col0 + 1;   // the bit of flat pixel "column W" = (row+1, 0): column 0, never a source
+        if (e <= 9) b &= ~(1u << e);  // (bits above it only reach outputs past the row's end)
         r.bits = b;
     }
     __device__ __forceinline__ void compute(const MRow8 &u, const MRow8 &m, const MRow8 &d, uint32_t o[2]) const {
@@ -596,9 +597,9 @@ inline uint32_t se_mask3(const int *se) {
 }
 
 // the 8-pixel path needs 4-byte aligned rows and chunks, and 32-bit flat offsets
-inline bool fast8_ok(const uint8_t *in, const uint8_t *out, int W, int H, long long in_stride, long long out_stride) {
-    return (W % 8 == 0) && (reinterpret_cast<uintptr_t>(in) % 4 == 0) && (reinterpret_cast<uintptr_t>(out) % 8 == 0) &&
-           in_stride % 4 == 0 && out_stride % 8 == 0 && (long long)W * H < (1LL << 30);
+// the 8-pixel 3x3 path: any alignment, widths from 8 up (32-bit flat offsets inside the kernel)
+inline bool fast8_ok(const uint8_t *, const uint8_t *, int W, int H, long long, long long) {
+    return W >= 8 && (long long)W * H < (1LL << 30);
 }
 
 }  // namespace iak

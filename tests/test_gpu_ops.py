@@ -411,3 +411,52 @@ def test_median3_weighted(ops, weights, W, H, kind):
     bisection path behind it (a weight of 256, widths that are not a multiple of 8)."""
     imgs = batch(kind, W, H, 2)
     each(lambda x: ops.medianFilter(x, weights, 3, 3), lambda x: O.median(x, weights, 3, 3), imgs)
+
+
+@pytest.mark.parametrize("W", list(range(8, 42)) + [67, 250, 770])
+def test_stencils3_any_width_and_alignment(ops, W):
+    """The 3x3 operations on widths that are no multiple of 8, with images and outputs at odd byte
+    offsets and strides: results as the oracle's, and not one byte written outside the images."""
+    from imageanalysis_amd import lib as L
+    lib = L.load()
+    rs = np.random.default_rng(W)
+    stream = torch.cuda.current_stream().cuda_stream
+    k_f = np.array([0.1, 0.2, 0.05, 0.3, 0.15, 0.02, 0.08, 0.07, 0.03], np.float32)
+    k_w = np.array([1, 2, 1, 2, 3, 2, 1, 2, 1], np.int32)
+    k_1 = np.ones(9, np.int32)
+    k_se = np.array([0, 1, 0, 1, 1, 1, 0, 1, 1], np.int32)
+    for H in (1, 2, 9, 26):
+        B, N = 2, W * H
+        imgs = batch("U", W, H, B)
+        imgs[rs.random(imgs.shape) < 0.3] = 0
+        in_off, out_off = int(rs.integers(0, 8)), int(rs.integers(0, 8))
+        in_stride, out_stride = N + int(rs.integers(0, 6)), N + int(rs.integers(0, 6))
+        src = torch.zeros(in_off + in_stride * B + 16, dtype=torch.uint8, device="cuda")
+        x = torch.as_strided(src[in_off:], (B, H, W), (in_stride, W, 1))
+        x.copy_(dev(imgs))
+        cases = [
+            ("sobel", lambda i, o: lib.iak_sobel(i, o, W, H, B, in_stride, out_stride, stream), O.sobel),
+            ("compass", lambda i, o: lib.iak_compass(i, o, W, H, B, in_stride, out_stride, stream), O.compass),
+            ("median", lambda i, o: lib.iak_median(i, o, W, H, B, in_stride, out_stride, k_1.ctypes.data, 3, 3, stream),
+             lambda a: O.median(a, k_1, 3, 3)),
+            ("wmedian", lambda i, o: lib.iak_median(i, o, W, H, B, in_stride, out_stride, k_w.ctypes.data, 3, 3, stream),
+             lambda a: O.median(a, k_w, 3, 3)),
+            ("linear", lambda i, o: lib.iak_linear(i, o, W, H, B, in_stride, out_stride, k_f.ctypes.data, 3, 3,
+                                                   L.IAK_LINEAR_CLAMP, stream), lambda a: O.linear(a, k_f, 3, 3)),
+            ("average", lambda i, o: lib.iak_linear(i, o, W, H, B, in_stride, out_stride, k_f.ctypes.data, 3, 3,
+                                                    L.IAK_LINEAR_AVERAGE, stream), lambda a: O.average(a, k_f, 3, 3)),
+            ("erode", lambda i, o: lib.iak_erode(i, o, W, H, B, in_stride, out_stride, k_se.ctypes.data, 3, 3, stream),
+             lambda a: O.erode(a, k_se, 3, 3)),
+            ("dilate", lambda i, o: lib.iak_dilate(i, o, W, H, B, in_stride, out_stride, k_se.ctypes.data, 3, 3, stream),
+             lambda a: O.dilate(a, k_se, 3, 3)),
+        ]
+        for name, run, ref in cases:
+            dst = torch.full((out_off + out_stride * B + 16,), 0xA5, dtype=torch.uint8, device="cuda")
+            L.check(run(x.data_ptr(), dst.data_ptr() + out_off), name)
+            got = host(dst)
+            expect = np.full(got.shape, 0xA5, np.uint8)
+            for b in range(B):
+                expect[out_off + b * out_stride: out_off + b * out_stride + N] = ref(imgs[b]).reshape(-1)
+            bad = np.flatnonzero(got != expect)
+            assert bad.size == 0, (f"{name} {W}x{H} in+{in_off}/{in_stride} out+{out_off}/{out_stride}: {bad.size} bytes "
+                                   f"differ, first at {bad[0]} (got {got[bad[0]]}, want {expect[bad[0]]})")
