@@ -491,7 +491,7 @@ static int plan(iak_pipeline *p) {
         for (size_t k = 1; k < p->groups.size(); k++) {
             if (p->groups[k].kind != G_HIST) continue;
             Group &prev = p->groups[k - 1];
-            const bool stencil_ok = prev.kind == G_OP && is_fusable_stencil(p->ops[prev.op_index].op) && p->W % 8 == 0 &&
+            const bool stencil_ok = prev.kind == G_OP && is_fusable_stencil(p->ops[prev.op_index].op) && p->W >= 8 &&
                                     (long long)p->W * p->H < (1LL << 30);
             if (prev.kind != G_CHAIN && !stencil_ok) continue;
             prev.emit_hist = true;

@@ -258,9 +258,9 @@ static int launch_tiled_morph(const uint8_t *in, uint8_t *out, int W, int H, int
 // Median, all weights 1, kW x kH <= 255 taps: Huang's sliding histogram, one lane per image
 // column.  A lane keeps the 256-bin histogram of its window in LDS (byte counters packed four
 // to a word, word w of lane l at w * LANES + l so that a lane only ever touches bank l % 32)
-// plus a 16-bin coarse histogram (16 values per bin); moving down one row takes kW pixels
-// out and kW in, and the median is found by one pass over the coarse counts and one over
-// the 16 fine counts of the bin it falls in: O(kW) work per pixel instead of O(kW * kH).
+// plus four coarse counters (64 values each) in a register; moving down one row takes kW
+// pixels out and kW in, and the median is found from the coarse counters, then the sums of
+// the 16 fine words of that quarter, then one word: O(kW) work per pixel instead of O(kW * kH).
 // The result is the smallest v with #(window <= v) > taps/2, i.e. sorted[taps/2]
 // (imageAnalysis.cu:641-680 with a race-free private window).
 // ---------------------------------------------------------------------------------------
@@ -268,17 +268,33 @@ static int launch_tiled_morph(const uint8_t *in, uint8_t *out, int W, int H, int
 #define HM_STRIP 64
 #define HM_MAXHALO 24  // kW <= 25
 #define HM_ROWBUF (HM_LANES + HM_MAXHALO + 8)
-__device__ __forceinline__ void hm_update(uint32_t *fine, uint32_t *coarse, uint32_t v, bool add) {
-    // word and byte of value v in the fine table (4 values per word) and of its 16-value bin in
-    // the coarse table; a lane's words are HM_LANES words apart
-    uint32_t f = 1u << ((v << 3) & 24u), c = 1u << ((v >> 1) & 24u);
-    if (!add) { f = 0u - f; c = 0u - c; }  // taking a pixel out adds the two's complement
-    // A lane owns its words, so nothing races; LDS add instructions without a return value are
-    // used because they are fire-and-forget, where a read-modify-write would serialise every
-    // update behind an LDS round trip.
-    atomicAdd(fine + (v >> 2) * HM_LANES, f);
-    atomicAdd(coarse + (v >> 6) * HM_LANES, c);
+// One pixel into (ADD) or out of a lane's histograms.  `x` holds the pixel value in its low 8
+// bits; whatever lies above them is ignored, so callers pass a shifted word of packed pixels.
+// Counters are bytes, four to a word, in REVERSED order inside the word (value v of a fine
+// word sits in byte 3 - (v & 3), the coarse count of the values [64k, 64k+64) in byte 3 - k of
+// the register c64): the one-hot increment is then a single byte-align of a constant by the
+// low two bits of its operand.
+// A lane owns its words (word w of lane l at w * HM_LANES + l, so a lane only ever touches
+// bank l % 32) and nothing races; LDS add/sub instructions without a return value are used
+// because they are fire-and-forget, where a read-modify-write would serialise every update
+// behind an LDS round trip.  Those instructions are what bounds the kernel (about 16 cycles
+// per wave each), which is why the coarse level is four counters in a register and not a
+// second table in LDS.
+template <bool ADD>
+__device__ __forceinline__ void hm_update(uint32_t *fine, uint32_t &c64, uint32_t x) {
+    const uint32_t f = __builtin_amdgcn_alignbyte(0u, 0x01000000u, x);       // 1 << 8 * (3 - (v & 3))
+    const uint32_t c = __builtin_amdgcn_alignbyte(0u, 0x01000000u, x >> 6);  // 1 << 8 * (3 - (v >> 6))
+    uint32_t *fw = fine + ((x >> 2) & 63u) * HM_LANES;                       // fine word v >> 2
+    if (ADD) {
+        atomicAdd(fw, f);
+        c64 += c;
+    } else {
+        atomicSub(fw, f);
+        c64 -= c;
+    }
 }
+// the counters of a word in ascending order of value
+__device__ __forceinline__ uint32_t hm_ascending(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x00010203u); }
 // 16 byte counters packed in w[0..3]; `need` (>= 1) is how many more pixels, counted from the
 // first counter, the sought position lies: returns the index of the counter that holds it and
 // in *before the total of the counters in front of that one.  The caller guarantees that the
@@ -295,18 +311,31 @@ __device__ __forceinline__ uint32_t hm_find16(const uint32_t w[4], uint32_t need
     return 4 * k + b;
 }
 
+// One tap through the image's buffer descriptor: flat offsets outside [0, N) read 0.  The
+// offset is clamped to N in a register first so that the compiler cannot split it into a
+// negative register part and a positive immediate: the range check is done on the unwrapped
+// sum, and such a pair would read 0 for a tap that is inside the image.
+__device__ __forceinline__ uint32_t hm_tap(__amdgpu_buffer_rsrc_t rsrc, int offset, int N) {
+    const uint32_t o = min((uint32_t)offset, (uint32_t)N);
+    return __builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)o, 0, 0);
+}
+
+template <int KW>
 __global__ __launch_bounds__(HM_LANES) void huang_median_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                                 int W, int H, long long in_stride, long long out_stride,
-                                                                int kW, int kH, int strips_x) {
+                                                                int kH, int strips_x) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hm_lds[];
-    uint32_t *fine = hm_lds + threadIdx.x;                    // [64][LANES]
-    uint32_t *coarse = hm_lds + 64 * HM_LANES + threadIdx.x;  // [4][LANES]
+    uint32_t *fine = hm_lds + threadIdx.x;  // [64][LANES]
     // the row that enters and the row that leaves, columns cx0-s .. cx0+LANES-1+s, loaded once
     // per workgroup and step (double buffered: the next step's rows are fetched a step early)
-    uint8_t *rowbuf = reinterpret_cast<uint8_t *>(hm_lds + 68 * HM_LANES);  // [2 steps][2 rows][HM_ROWBUF]
-    const long long N = (long long)W * H;
+    uint8_t *rowbuf = reinterpret_cast<uint8_t *>(hm_lds + 64 * HM_LANES);  // [2 steps][2 rows][HM_ROWBUF]
+    const int N = W * H;  // the launcher keeps W * (H + 32) below 2^31
     const uint8_t *src = in + (long long)blockIdx.y * in_stride;
     uint8_t *dst = out + (long long)blockIdx.y * out_stride;
+    // Taps come through a buffer descriptor over exactly the image: a flat offset outside
+    // [0, N) -- negative ones included, as unsigned -- reads 0 without a branch.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
+    constexpr int kW = KW;
     const int a = (kH - 1) / 2, s = (kW - 1) / 2;
     const int sy = blockIdx.x / strips_x, sx = blockIdx.x - sy * strips_x;
     const int cx0 = sx * HM_LANES;
@@ -316,60 +345,93 @@ __global__ __launch_bounds__(HM_LANES) void huang_median_kernel(const uint8_t *_
     const int y1 = (y0 + HM_STRIP < H) ? y0 + HM_STRIP : H;
     const bool live = col < W && !(col < s || col > W - s);  // border columns produce zeros
 #pragma unroll 8
-    for (int w = 0; w < 64; w++) fine[w * HM_LANES] = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) coarse[w * HM_LANES] = 0;
+    for (int w = 0; w < 64; w++) fine[w * HM_LANES] = 0;  // the fine words
+    uint32_t c64 = 0;
     const uint32_t need = (uint32_t)(kW * kH) / 2 + 1;  // position of sorted[taps / 2], counted from 1
-    // window of the strip's first row
-    if (live)
-        for (int i = y0 - a; i <= y0 + a; i++)
-            for (int j = col - s; j <= col + s; j++) hm_update(fine, coarse, tap_at(src, N, (long long)i * W + j), true);
-    // rows for the first slide (row y0-a leaves, row y0+1+a enters)
-    const int extra = lane < 2 * s ? HM_LANES + lane : -1;  // the halo columns are fetched by the first 2s lanes
-    uint32_t top0, bot0, top1 = 0, bot1 = 0;
-    {
-        const long long top = (long long)(y0 - a) * W + (cx0 - s), bot = (long long)(y0 + 1 + a) * W + (cx0 - s);
-        top0 = tap_at(src, N, top + lane);
-        bot0 = tap_at(src, N, bot + lane);
-        if (extra >= 0) {
-            top1 = tap_at(src, N, top + extra);
-            bot1 = tap_at(src, N, bot + extra);
+    // window of the strip's first row: a row of taps in flight at a time
+    if (live) {
+        int off = (y0 - a) * W + col - s;
+        for (int i = 0; i < kH; i++, off += W) {
+            uint32_t v[KW];
+#pragma unroll
+            for (int j = 0; j < KW; j++) v[j] = hm_tap(rsrc, off + j, N);
+#pragma unroll
+            for (int j = 0; j < KW; j++) hm_update<true>(fine, c64, v[j]);
         }
     }
-    for (int y = y0; y < y1; y++) {
+    // rows for the first slide (row y0-a leaves, row y0+1+a enters); the 2s halo columns to the
+    // right are fetched by the first 2s lanes (everyone else asks for offset N: out of range)
+    const bool has_extra = lane < 2 * s;
+    int top = (y0 - a) * W + (cx0 - s) + lane, bot = (y0 + 1 + a) * W + (cx0 - s) + lane;
+    uint32_t top0 = hm_tap(rsrc, top, N);
+    uint32_t bot0 = hm_tap(rsrc, bot, N);
+    uint32_t top1 = hm_tap(rsrc, has_extra ? top + HM_LANES : N, N);
+    uint32_t bot1 = hm_tap(rsrc, has_extra ? bot + HM_LANES : N, N);
+    uint8_t *q = dst + (long long)y0 * W + col;
+    for (int y = y0; y < y1; y++, q += W) {
         uint8_t *rb = rowbuf + ((y - y0) & 1) * (2 * HM_ROWBUF);
         rb[lane] = (uint8_t)top0;
         rb[HM_ROWBUF + lane] = (uint8_t)bot0;
-        if (extra >= 0) {
-            rb[extra] = (uint8_t)top1;
-            rb[HM_ROWBUF + extra] = (uint8_t)bot1;
+        if (has_extra) {
+            rb[HM_LANES + lane] = (uint8_t)top1;
+            rb[HM_ROWBUF + HM_LANES + lane] = (uint8_t)bot1;
         }
-        if (y + 2 < y1) {  // fetch the rows of the next slide now, use them after the next barrier
-            const long long top = (long long)(y + 1 - a) * W + (cx0 - s), bot = (long long)(y + 2 + a) * W + (cx0 - s);
-            top0 = tap_at(src, N, top + lane);
-            bot0 = tap_at(src, N, bot + lane);
-            if (extra >= 0) {
-                top1 = tap_at(src, N, top + extra);
-                bot1 = tap_at(src, N, bot + extra);
-            }
-        }
+        // fetch the rows of the next slide now, use them after the next barrier (past the
+        // strip's end they are never used, and past the image's end they read 0)
+        top += W;
+        bot += W;
+        top0 = hm_tap(rsrc, top, N);
+        bot0 = hm_tap(rsrc, bot, N);
+        top1 = hm_tap(rsrc, has_extra ? top + HM_LANES : N, N);
+        bot1 = hm_tap(rsrc, has_extra ? bot + HM_LANES : N, N);
         uint32_t o = 0;
         if (live && !(y < a || y > H - a)) {
-            uint32_t cw[4], fw[4], before, unused;
+            // which quarter of the value range holds the sought position, from the register
+            const uint32_t p = hm_ascending(c64) * 0x01010101u;  // byte-wise inclusive prefix sums
+            const uint32_t k = ((p & 0xffu) < need ? 1u : 0u) + (((p >> 8) & 0xffu) < need ? 1u : 0u) +
+                               (((p >> 16) & 0xffu) < need ? 1u : 0u);
+            const uint32_t need1 = need - (((p << 8) >> (8 * k)) & 0xffu);
+            // its 16 fine words, summed four at a time (byte-wise: totals stay below 256)
+            uint32_t fw[16], t[4];
 #pragma unroll
-            for (int w = 0; w < 4; w++) cw[w] = coarse[w * HM_LANES];
-            const uint32_t cb = hm_find16(cw, need, &before);
+            for (int w = 0; w < 16; w++) fw[w] = fine[(k * 16 + w) * HM_LANES];
 #pragma unroll
-            for (int w = 0; w < 4; w++) fw[w] = fine[(cb * 4 + w) * HM_LANES];
-            const uint32_t fb = hm_find16(fw, need - before, &unused);
-            o = cb * 16 + fb;
+            for (int g = 0; g < 4; g++)
+                t[g] = ((fw[4 * g] + fw[4 * g + 1] + fw[4 * g + 2] + fw[4 * g + 3]) * 0x01010101u) >> 24;
+            const uint32_t T0 = t[0], T1 = T0 + t[1], T2 = T1 + t[2];
+            const uint32_t g = (T0 < need1 ? 1u : 0u) + (T1 < need1 ? 1u : 0u) + (T2 < need1 ? 1u : 0u);
+            const uint32_t base = g == 0 ? 0u : (g == 1 ? T0 : (g == 2 ? T1 : T2));
+            uint32_t sel[4], unused;
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                sel[w] = hm_ascending(g == 0 ? fw[w] : (g == 1 ? fw[4 + w] : (g == 2 ? fw[8 + w] : fw[12 + w])));
+            o = k * 64 + g * 16 + hm_find16(sel, need1 - base, &unused);
         }
-        if (col < W) dst[(long long)y * W + col] = (uint8_t)o;
+        if (col < W) *q = (uint8_t)o;
         __syncthreads();  // this step's rows are in rowbuf
         if (live && y + 1 < y1) {
-            for (int j = 0; j < kW; j++) {
-                hm_update(fine, coarse, rb[lane + j], false);
-                hm_update(fine, coarse, rb[HM_ROWBUF + lane + j], true);
+            // the lane's kW pixels of either row: whole words read at once, then shifted so that
+            // byte 0 is the lane's own column (one LDS round trip per step, not one per pixel)
+            constexpr int NA = (KW + 3) / 4;
+            const uint32_t *rw = reinterpret_cast<const uint32_t *>(rb) + (lane >> 2);
+            uint32_t tw[NA + 1], bw[NA + 1];
+#pragma unroll
+            for (int w = 0; w <= NA; w++) {
+                tw[w] = rw[w];
+                bw[w] = rw[HM_ROWBUF / 4 + w];
+            }
+            const uint32_t sh = (uint32_t)lane & 3u;
+#pragma unroll
+            for (int qd = 0; qd < NA; qd++) {
+                const uint32_t t = __builtin_amdgcn_alignbyte(tw[qd + 1], tw[qd], sh);
+                const uint32_t b = __builtin_amdgcn_alignbyte(bw[qd + 1], bw[qd], sh);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (4 * qd + j < KW) {
+                        hm_update<false>(fine, c64, t >> (8 * j));
+                        hm_update<true>(fine, c64, b >> (8 * j));
+                    }
+                }
             }
         }
     }
@@ -377,11 +439,21 @@ __global__ __launch_bounds__(HM_LANES) void huang_median_kernel(const uint8_t *_
 
 static int launch_huang_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
                                long long out_stride, int kW, int kH, hipStream_t s) {
-    if (kW * kH > 255 || (long long)W * H >= (1LL << 31)) return IAK_E_UNSUPPORTED;
+    if (kW * kH > 255 || (long long)W * ((long long)H + 32) >= (1LL << 31)) return IAK_E_UNSUPPORTED;
     const int strips_x = (W + HM_LANES - 1) / HM_LANES, strips_y = (H + HM_STRIP - 1) / HM_STRIP;
-    const size_t lds = sizeof(uint32_t) * 68 * HM_LANES + 4 * HM_ROWBUF;
-    hipLaunchKernelGGL(huang_median_kernel, dim3((unsigned)(strips_x * strips_y), B), dim3(HM_LANES), lds, s, in, out, W, H,
-                       in_stride, out_stride, kW, kH, strips_x);
+    const size_t lds = sizeof(uint32_t) * 64 * HM_LANES + 4 * HM_ROWBUF;
+    const dim3 grid((unsigned)(strips_x * strips_y), B);
+#define HM_CASE(K)                                                                                                     \
+    case K:                                                                                                            \
+        hipLaunchKernelGGL(huang_median_kernel<K>, grid, dim3(HM_LANES), lds, s, in, out, W, H, in_stride, out_stride, kH, \
+                           strips_x);                                                                                  \
+        break;
+    switch (kW) {
+        HM_CASE(1) HM_CASE(3) HM_CASE(5) HM_CASE(7) HM_CASE(9) HM_CASE(11) HM_CASE(13) HM_CASE(15) HM_CASE(17)
+        HM_CASE(19) HM_CASE(21) HM_CASE(23) HM_CASE(25)
+    default: return IAK_E_UNSUPPORTED;
+    }
+#undef HM_CASE
     IAK_LAUNCH_CHECK();
     return 0;
 }

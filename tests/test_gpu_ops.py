@@ -281,6 +281,14 @@ def test_median_sliding_histogram(ops, kW, kH, W, H, kind):
     each(lambda x: ops.medianFilter(x, w, kW, kH), lambda x: O.median(x, w, kW, kH), imgs)
 
 
+@pytest.mark.parametrize("kW,kH", [(51, 5), (255, 1), (1, 255), (27, 9)])
+def test_median_wide_windows(ops, kW, kH):
+    # at most 255 taps but wider than the sliding-histogram kernel's 25 columns: the bisection kernel takes them
+    imgs = batch("U", 300, 40, 1) if kH < 100 else batch("U", 20, 300, 1)
+    w = [1] * (kW * kH)
+    each(lambda x: ops.medianFilter(x, w, kW, kH), lambda x: O.median(x, w, kW, kH), imgs)
+
+
 def test_median_above_255_taps_uses_bisection(ops):
     imgs = batch("U", 70, 40, 1)
     w = [1] * (17 * 17)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time an operation list through the executor in its three modes on the bench batch.
-usage: python tools/pipebench.py light|pa|pc|morph"""
+usage: python tools/pipebench.py [--size WxH] light|pa|input|morph ..."""
 import sys, os
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,9 +25,13 @@ CASES = {
         {"type": 14}, {"type": 15}],
 }
 B = 500
+args = sys.argv[1:]
+if args and args[0] == "--size":
+    bench.W, bench.H = (int(v) for v in args[1].lower().split("x"))
+    args = args[2:]
 rgb = bench.make_cell_batch(B, torch.device("cuda"), 1)
 out = torch.empty((B, bench.H, bench.W), dtype=torch.uint8, device="cuda")
-for name in sys.argv[1:]:
+for name in args:
     for mode in [False, "pointwise", True, "strips"]:
         p = Pipeline(bench.W, bench.H, B, CASES[name], fused=mode)
         p.bind_features(torch.zeros((B, 7), dtype=torch.float32, device="cuda"))
