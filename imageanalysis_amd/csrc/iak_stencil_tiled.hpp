@@ -264,8 +264,12 @@ static int launch_tiled_morph(const uint8_t *in, uint8_t *out, int W, int H, int
 // The result is the smallest v with #(window <= v) > taps/2, i.e. sorted[taps/2]
 // (imageAnalysis.cu:641-680 with a race-free private window).
 // ---------------------------------------------------------------------------------------
-#define HM_LANES 128
+#ifndef HM_LANES
+#define HM_LANES 64
+#endif
+#ifndef HM_STRIP
 #define HM_STRIP 64
+#endif
 #define HM_MAXHALO 24  // kW <= 25
 #define HM_ROWBUF (HM_LANES + HM_MAXHALO + 8)
 // One pixel into (ADD) or out of a lane's histograms.  `x` holds the pixel value in its low 8
@@ -295,20 +299,31 @@ __device__ __forceinline__ void hm_update(uint32_t *fine, uint32_t &c64, uint32_
 }
 // the counters of a word in ascending order of value
 __device__ __forceinline__ uint32_t hm_ascending(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x00010203u); }
-// 16 byte counters packed in w[0..3]; `need` (>= 1) is how many more pixels, counted from the
-// first counter, the sought position lies: returns the index of the counter that holds it and
-// in *before the total of the counters in front of that one.  The caller guarantees that the
-// 16 counters together hold at least `need`; totals never exceed 255.
-__device__ __forceinline__ uint32_t hm_find16(const uint32_t w[4], uint32_t need, uint32_t *before) {
-    const uint32_t p0 = w[0] * 0x01010101u, p1 = w[1] * 0x01010101u, p2 = w[2] * 0x01010101u, p3 = w[3] * 0x01010101u;
-    const uint32_t t0 = p0 >> 24, t1 = t0 + (p1 >> 24), t2 = t1 + (p2 >> 24);  // totals through word 0, 1, 2
+// byte-wise helpers on four packed counters (totals never exceed 255, so no byte overflows)
+__device__ __forceinline__ uint32_t hm_prefix4(uint32_t x) {  // inclusive prefix sums, byte by byte
+    const uint32_t y = x + (x << 8);
+    return y + (y << 16);
+}
+__device__ __forceinline__ uint32_t hm_sum4(uint32_t x) { return __builtin_amdgcn_sad_u8(x, 0u, 0u); }
+// how many of the first three bytes of p are below need
+__device__ __forceinline__ uint32_t hm_below3(uint32_t p, uint32_t need) {
+    return ((p & 0xffu) < need ? 1u : 0u) + (((p >> 8) & 0xffu) < need ? 1u : 0u) + (((p >> 16) & 0xffu) < need ? 1u : 0u);
+}
+// x[i] for i in [0, 4), as two levels of selects on values already in registers
+__device__ __forceinline__ uint32_t hm_pick(uint32_t i, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+    const bool b0 = (i & 1u) != 0, b1 = (i & 2u) != 0;
+    const uint32_t lo = b0 ? x1 : x0, hi = b0 ? x3 : x2;
+    return b1 ? hi : lo;
+}
+// 16 byte counters packed in w[0..3], ascending; `need` (>= 1) is how many more pixels, counted
+// from the first counter, the sought position lies: returns the index of the counter that
+// holds it.  The caller guarantees that the 16 counters together hold at least `need`.
+__device__ __forceinline__ uint32_t hm_find16(const uint32_t w[4], uint32_t need) {
+    const uint32_t t0 = hm_sum4(w[0]), t1 = t0 + hm_sum4(w[1]), t2 = t1 + hm_sum4(w[2]);  // totals through word 0, 1, 2
     const uint32_t k = (t0 < need ? 1u : 0u) + (t1 < need ? 1u : 0u) + (t2 < need ? 1u : 0u);
-    const uint32_t base = k == 0 ? 0u : (k == 1 ? t0 : (k == 2 ? t1 : t2));
-    const uint32_t p = k == 0 ? p0 : (k == 1 ? p1 : (k == 2 ? p2 : p3));  // byte-wise inclusive prefix sums of word k
-    const uint32_t r = need - base;                                         // 1 <= r <= 255
-    const uint32_t b = ((p & 0xffu) < r ? 1u : 0u) + (((p >> 8) & 0xffu) < r ? 1u : 0u) + (((p >> 16) & 0xffu) < r ? 1u : 0u);
-    *before = base + (((p << 8) >> (8 * b)) & 0xffu);
-    return 4 * k + b;
+    const uint32_t base = hm_pick(k, 0u, t0, t1, t2);
+    const uint32_t p = hm_prefix4(hm_pick(k, w[0], w[1], w[2], w[3]));
+    return 4 * k + hm_below3(p, need - base);
 }
 
 // One tap through the image's buffer descriptor: flat offsets outside [0, N) read 0.  The
@@ -387,25 +402,21 @@ __global__ __launch_bounds__(HM_LANES) void huang_median_kernel(const uint8_t *_
         uint32_t o = 0;
         if (live && !(y < a || y > H - a)) {
             // which quarter of the value range holds the sought position, from the register
-            const uint32_t p = hm_ascending(c64) * 0x01010101u;  // byte-wise inclusive prefix sums
-            const uint32_t k = ((p & 0xffu) < need ? 1u : 0u) + (((p >> 8) & 0xffu) < need ? 1u : 0u) +
-                               (((p >> 16) & 0xffu) < need ? 1u : 0u);
+            const uint32_t p = hm_prefix4(hm_ascending(c64));
+            const uint32_t k = hm_below3(p, need);
             const uint32_t need1 = need - (((p << 8) >> (8 * k)) & 0xffu);
             // its 16 fine words, summed four at a time (byte-wise: totals stay below 256)
-            uint32_t fw[16], t[4];
+            uint32_t fw[16];
 #pragma unroll
             for (int w = 0; w < 16; w++) fw[w] = fine[(k * 16 + w) * HM_LANES];
-#pragma unroll
-            for (int g = 0; g < 4; g++)
-                t[g] = ((fw[4 * g] + fw[4 * g + 1] + fw[4 * g + 2] + fw[4 * g + 3]) * 0x01010101u) >> 24;
-            const uint32_t T0 = t[0], T1 = T0 + t[1], T2 = T1 + t[2];
+            const uint32_t T0 = hm_sum4(fw[0] + fw[1] + fw[2] + fw[3]), T1 = T0 + hm_sum4(fw[4] + fw[5] + fw[6] + fw[7]),
+                           T2 = T1 + hm_sum4(fw[8] + fw[9] + fw[10] + fw[11]);
             const uint32_t g = (T0 < need1 ? 1u : 0u) + (T1 < need1 ? 1u : 0u) + (T2 < need1 ? 1u : 0u);
-            const uint32_t base = g == 0 ? 0u : (g == 1 ? T0 : (g == 2 ? T1 : T2));
-            uint32_t sel[4], unused;
+            const uint32_t base = hm_pick(g, 0u, T0, T1, T2);
+            uint32_t sel[4];
 #pragma unroll
-            for (int w = 0; w < 4; w++)
-                sel[w] = hm_ascending(g == 0 ? fw[w] : (g == 1 ? fw[4 + w] : (g == 2 ? fw[8 + w] : fw[12 + w])));
-            o = k * 64 + g * 16 + hm_find16(sel, need1 - base, &unused);
+            for (int w = 0; w < 4; w++) sel[w] = hm_ascending(hm_pick(g, fw[w], fw[4 + w], fw[8 + w], fw[12 + w]));
+            o = k * 64 + g * 16 + hm_find16(sel, need1 - base);
         }
         if (col < W) *q = (uint8_t)o;
         __syncthreads();  // this step's rows are in rowbuf
