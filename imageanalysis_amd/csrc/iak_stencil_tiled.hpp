@@ -35,23 +35,33 @@ __device__ __forceinline__ uint32_t tap_at(const uint8_t *img, long long N, long
 // ---------------------------------------------------------------------------------------
 #define TL_TW 64
 #define TL_TH 32
-template <int KW, bool AVG>
+// UNIFORM: all taps equal (a box filter).  The product pixel * tap then depends on the pixel
+// only, so the tile is staged as those products (floats) and a tap costs an add and a
+// truncation.  (Packed two-float multiplies and adds were measured: slower than the plain
+// ones here.)
+template <int KW, bool AVG, bool UNIFORM>
 __global__ __launch_bounds__(256) void tiled_linear_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
                                                            int H, long long in_stride, long long out_stride, int kH,
                                                            int divisor, int tiles_x, Taps taps) {
-    constexpr int PITCH = ((TL_TW + KW - 1 + 3) / 4) * 4 + ((((TL_TW + KW - 1 + 3) / 4) & 1) ? 0 : 4);  // odd number of dwords
+    constexpr int COLS = TL_TW + KW - 1;
+    // bytes: an odd number of dwords per row; floats: a multiple of 4 plus 4 (16-byte rows, skewed banks)
+    constexpr int PITCH = UNIFORM ? ((COLS + 3) / 4) * 4 + 4 : ((COLS + 3) / 4) * 4 + ((((COLS + 3) / 4) & 1) ? 0 : 4);
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    float *tilef = reinterpret_cast<float *>(tile);
     const long long N = (long long)W * H;
     const uint8_t *src = in + (long long)blockIdx.y * in_stride;
     uint8_t *dst = out + (long long)blockIdx.y * out_stride;
     const int a = (kH - 1) / 2, s = (KW - 1) / 2;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int x0 = tx * TL_TW, y0 = ty * TL_TH;
-    const int rows = TL_TH + kH - 1, cols = TL_TW + KW - 1;
-    for (int e = threadIdx.x; e < rows * cols; e += 256) {
-        const int r = e / cols, c = e - r * cols;
+    const int rows = TL_TH + kH - 1;
+    const float k0 = taps.f[0];
+    for (int e = threadIdx.x; e < rows * COLS; e += 256) {
+        const int r = e / COLS, c = e - r * COLS;
         const long long idx = (long long)(y0 - a + r) * W + (x0 - s + c);
-        tile[r * PITCH + c] = (uint8_t)tap_at(src, N, idx);
+        const uint32_t v = tap_at(src, N, idx);
+        if (UNIFORM) tilef[r * PITCH + c] = (float)v * k0;
+        else tile[r * PITCH + c] = (uint8_t)v;
     }
     __syncthreads();
     const int lx = threadIdx.x & 7, ly = threadIdx.x >> 3;
@@ -63,21 +73,30 @@ __global__ __launch_bounds__(256) void tiled_linear_kernel(const uint8_t *__rest
     constexpr int NPX = 8 + KW - 1;
     constexpr int NW = (NPX + 3) / 4;
     for (int r = 0; r < kH; r++) {
-        const uint32_t *rp = reinterpret_cast<const uint32_t *>(tile + (ly + r) * PITCH + lx * 8);
         float px[NW * 4];
+        if (UNIFORM) {
+            const float4 *rp = reinterpret_cast<const float4 *>(tilef + (ly + r) * PITCH + lx * 8);
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            const uint32_t v = rp[w];
-            px[4 * w + 0] = (float)(v & 0xffu);
-            px[4 * w + 1] = (float)((v >> 8) & 0xffu);
-            px[4 * w + 2] = (float)((v >> 16) & 0xffu);
-            px[4 * w + 3] = (float)(v >> 24);
+            for (int w = 0; w < NW; w++) {
+                const float4 v = rp[w];
+                px[4 * w + 0] = v.x; px[4 * w + 1] = v.y; px[4 * w + 2] = v.z; px[4 * w + 3] = v.w;
+            }
+        } else {
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(tile + (ly + r) * PITCH + lx * 8);
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const uint32_t v = rp[w];
+                px[4 * w + 0] = (float)(v & 0xffu);
+                px[4 * w + 1] = (float)((v >> 8) & 0xffu);
+                px[4 * w + 2] = (float)((v >> 16) & 0xffu);
+                px[4 * w + 3] = (float)(v >> 24);
+            }
         }
 #pragma unroll
         for (int j = 0; j < KW; j++) {
             const float k = taps.f[r * KW + j];
 #pragma unroll
-            for (int i = 0; i < 8; i++) sum[i] = __builtin_truncf(sum[i] + px[i + j] * k);
+            for (int i = 0; i < 8; i++) sum[i] = __builtin_truncf(UNIFORM ? sum[i] + px[i + j] : sum[i] + px[i + j] * k);
         }
     }
     uint32_t o[8];
@@ -90,8 +109,8 @@ __global__ __launch_bounds__(256) void tiled_linear_kernel(const uint8_t *__rest
         o[i] = is_border(row, col0 + i, W, H, a, s) ? 0u : r8;
     }
     uint8_t *q = dst + (long long)row * W + col0;
-    if (col0 + 8 <= W && ((reinterpret_cast<uintptr_t>(q) & 7u) == 0)) {
-        st8<true>(q, o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24), o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24));
+    if (col0 + 8 <= W) {
+        st8_unaligned(q, o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24), o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24));
     } else {
 #pragma unroll
         for (int i = 0; i < 8; i++)
@@ -100,23 +119,29 @@ __global__ __launch_bounds__(256) void tiled_linear_kernel(const uint8_t *__rest
 }
 
 template <int KW>
-static size_t tiled_linear_lds(int kH) {
-    constexpr int PITCH = ((TL_TW + KW - 1 + 3) / 4) * 4 + ((((TL_TW + KW - 1 + 3) / 4) & 1) ? 0 : 4);
-    return (size_t)(TL_TH + kH - 1) * PITCH + 16;  // the last row's dword reads may run a few bytes past its pixels
+static size_t tiled_linear_lds(int kH, bool uniform) {
+    constexpr int COLS = TL_TW + KW - 1;
+    const int pitch = uniform ? ((COLS + 3) / 4) * 4 + 4 : ((COLS + 3) / 4) * 4 + ((((COLS + 3) / 4) & 1) ? 0 : 4);
+    // the last row's word reads may run a few elements past its pixels
+    return ((size_t)(TL_TH + kH - 1) * pitch + 16) * (uniform ? sizeof(float) : 1);
 }
 
 template <int KW>
 static int launch_tiled_linear_kw(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
-                                  long long out_stride, int kH, int divisor, bool avg, const Taps &t, hipStream_t s) {
+                                  long long out_stride, int kH, int divisor, bool avg, bool uniform, const Taps &t,
+                                  hipStream_t s) {
     const int tiles_x = (W + TL_TW - 1) / TL_TW, tiles_y = (H + TL_TH - 1) / TL_TH;
     const dim3 grid((unsigned)(tiles_x * tiles_y), B);
-    const size_t lds = tiled_linear_lds<KW>(kH);
-    if (avg)
-        hipLaunchKernelGGL((tiled_linear_kernel<KW, true>), grid, dim3(256), lds, s, in, out, W, H, in_stride, out_stride, kH,
-                           divisor, tiles_x, t);
-    else
-        hipLaunchKernelGGL((tiled_linear_kernel<KW, false>), grid, dim3(256), lds, s, in, out, W, H, in_stride, out_stride, kH,
-                           divisor, tiles_x, t);
+    const size_t lds = tiled_linear_lds<KW>(kH, uniform);
+#define TL_LAUNCH(A, U)                                                                                              \
+    hipLaunchKernelGGL((tiled_linear_kernel<KW, A, U>), grid, dim3(256), lds, s, in, out, W, H, in_stride, out_stride, kH, \
+                       divisor, tiles_x, t)
+    if (avg) {
+        if (uniform) TL_LAUNCH(true, true); else TL_LAUNCH(true, false);
+    } else {
+        if (uniform) TL_LAUNCH(false, true); else TL_LAUNCH(false, false);
+    }
+#undef TL_LAUNCH
     IAK_LAUNCH_CHECK();
     return 0;
 }
@@ -132,7 +157,9 @@ static int launch_tiled_linear(const uint8_t *in, uint8_t *out, int W, int H, in
         mag += t.f[i] < 0 ? -(double)t.f[i] : (double)t.f[i];
     }
     if (mag * 255.0 >= 16777216.0) return IAK_E_UNSUPPORTED;  // sums must stay exact in float
-#define TL_CASE(K) case K: return launch_tiled_linear_kw<K>(in, out, W, H, B, in_stride, out_stride, kHe, divisor, avg, t, s);
+    bool uniform = true;
+    for (int i = 1; i < kWe * kHe; i++) uniform = uniform && t.f[i] == t.f[0];
+#define TL_CASE(K) case K: return launch_tiled_linear_kw<K>(in, out, W, H, B, in_stride, out_stride, kHe, divisor, avg, uniform, t, s);
     switch (kWe) {
         TL_CASE(1) TL_CASE(3) TL_CASE(5) TL_CASE(7) TL_CASE(9) TL_CASE(11) TL_CASE(13) TL_CASE(15) TL_CASE(17)
         TL_CASE(19) TL_CASE(21) TL_CASE(23) TL_CASE(25)
