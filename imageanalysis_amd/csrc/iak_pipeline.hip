@@ -194,6 +194,8 @@ __global__ __launch_bounds__(256) void hist_accumulate_kernel(const uint32_t *__
 namespace iak {
 int stencil3_with_hist(const iak_op &o, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
                        long long out_stride, uint32_t *hist, void *stream);  // iak_stencil.hip
+int morph_chain3(const iak_op *ops, int n, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+                 long long out_stride, uint32_t *hist, void *stream);  // iak_stencil.hip
 }
 
 using namespace iak;
@@ -208,13 +210,14 @@ struct OpCopy {
     std::vector<int> i;
 };
 
-enum GroupKind { G_GRAYHIST, G_HIST, G_CHAIN, G_OP, G_CHAIN_OP, G_FEATURES, G_STRIP };
+enum GroupKind { G_GRAYHIST, G_HIST, G_CHAIN, G_OP, G_CHAIN_OP, G_FEATURES, G_STRIP, G_MORPH };
 
 struct Group {
     GroupKind kind;
     std::string name;
     long long alg_bytes;  // algorithmic bytes per pixel of the operations in the group
-    int op_index = -1;    // G_OP
+    int op_index = -1;    // G_OP; G_MORPH: the first operation of the run
+    int n_ops = 1;        // G_MORPH: operations in the run
     ChainDesc chain;      // G_CHAIN, G_CHAIN_OP, G_STRIP (n == 0: no per-pixel run in front)
     bool chain_needs_hist = false;
     StripDesc strip;      // G_STRIP
@@ -463,6 +466,33 @@ static int plan(iak_pipeline *p) {
                 continue;
             }
         }
+        // a run of 3x3 erosions / dilations is one pass on bit masks
+        if ((p->mode == IAK_PIPE_FUSED || p->mode == IAK_PIPE_FUSED_STRIPS) && p->W % 8 == 0 &&
+            (long long)p->W * ((long long)p->H + 8) < (1LL << 30)) {
+            auto is_morph3 = [&](int k) {
+                const iak_op &q = p->ops[k].op;
+                return (q.type == IAK_OP_ERODE || q.type == IAK_OP_DILATE) && q.kW == 3 && q.kH == 3;
+            };
+            int run = 0;
+            while (i + run < n && run < 3 && is_morph3(i + run)) run++;
+            if (run >= 2) {
+                Group gm;
+                gm.kind = G_MORPH;
+                gm.op_index = i;
+                gm.n_ops = run;
+                gm.alg_bytes = 0;
+                gm.chain.n = 0;
+                for (int k = 0; k < run; k++) {
+                    gm.alg_bytes += op_alg_bytes(p->ops[i + k].op.type);
+                    if (k) gm.name += "+";
+                    gm.name += op_name(p->ops[i + k].op.type);
+                }
+                p->groups.push_back(gm);
+                hist_known = false;
+                i += run;
+                continue;
+            }
+        }
         Group g;
         g.kind = o.type == IAK_OP_FEATURES ? G_FEATURES : G_OP;
         g.op_index = i;
@@ -493,7 +523,7 @@ static int plan(iak_pipeline *p) {
             Group &prev = p->groups[k - 1];
             const bool stencil_ok = prev.kind == G_OP && is_fusable_stencil(p->ops[prev.op_index].op) && p->W >= 8 &&
                                     (long long)p->W * p->H < (1LL << 30);
-            if (prev.kind != G_CHAIN && !stencil_ok) continue;
+            if (prev.kind != G_CHAIN && prev.kind != G_MORPH && !stencil_ok) continue;
             prev.emit_hist = true;
             prev.alg_bytes += 1;
             prev.name += "+hist";
@@ -885,6 +915,25 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             rc = iak_features(cur, p->W, p->H, B, N, cur_hist, p->features_out + (size_t)b0 * IAK_N_FEATURES,
                               p->feat_ws + (size_t)b0 * (size_t)p->feat_ws_per_image, s);
             break;
+        case G_MORPH: {
+            iak_op run[3];
+            for (int k = 0; k < g.n_ops; k++) run[k] = p->ops[g.op_index + k].op;
+            rc = morph_chain3(run, g.n_ops, cur, dst, p->W, p->H, B, N, N, g.emit_hist ? sl.hist2 : nullptr, s);
+            if (rc == IAK_E_UNSUPPORTED && dst != sl.bufA && dst != sl.bufB && (cur == sl.bufA || cur == sl.bufB)) {
+                // the caller's output buffer is not aligned for the one-pass kernel: one operation
+                // at a time through the two intermediate buffers
+                const uint8_t *from = cur;
+                rc = 0;
+                for (int k = 0; k < g.n_ops && rc == 0; k++) {
+                    uint8_t *to = (k == g.n_ops - 1) ? dst : (from == sl.bufA ? sl.bufB : sl.bufA);
+                    rc = run_single_op(p, sl, run[k], from, to, B, nullptr, s);
+                    from = to;
+                }
+                if (rc == 0 && g.emit_hist) rc = iak_hist(dst, sl.hist2, N, B, N, s);
+            }
+            cur_hist = g.emit_hist ? sl.hist2 : nullptr;
+            break;
+        }
         case G_OP:
             if (g.emit_hist) {
                 rc = stencil3_with_hist(p->ops[g.op_index].op, cur, dst, p->W, p->H, B, N, N, sl.hist2, s);

@@ -14,6 +14,7 @@
 #include "iak_hist.hpp"
 #include "iak_stencil_ops.hpp"
 #include "iak_stencil_tiled.hpp"
+#include "iak_morph_chain.hpp"
 
 namespace iak {
 
@@ -375,6 +376,24 @@ int stencil3_with_hist(const iak_op &o, const uint8_t *in, uint8_t *out, int W, 
     }
     default: return IAK_E_UNSUPPORTED;
     }
+}
+
+// A run of two or three 3x3 erosions / dilations as one pass (for the executor; not part of the C
+// ABI).  hist may be null.  IAK_E_UNSUPPORTED when the run or the buffers do not qualify.
+int morph_chain3(const iak_op *ops, int n, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+                 long long out_stride, uint32_t *hist, void *stream) {
+    if (check_image_args(in, out, W, H, B, in_stride, out_stride)) return IAK_E_ARG;
+    if (n < 2 || n > MC_MAX_OPS) return IAK_E_UNSUPPORTED;
+    MorphChainDesc d;
+    d.n = n;
+    for (int k = 0; k < MC_MAX_OPS; k++) { d.mask[k] = 0; d.dilate[k] = 0; }
+    for (int k = 0; k < n; k++) {
+        const iak_op &o = ops[k];
+        if ((o.type != IAK_OP_ERODE && o.type != IAK_OP_DILATE) || o.kW != 3 || o.kH != 3 || !o.ikernel) return IAK_E_UNSUPPORTED;
+        d.mask[k] = se_mask3(o.ikernel);
+        d.dilate[k] = o.type == IAK_OP_DILATE;
+    }
+    return launch_morph_chain(in, out, W, H, B, in_stride, out_stride, d, hist, as_stream(stream));
 }
 
 }  // namespace iak

@@ -54,10 +54,20 @@ __device__ __forceinline__ uint32_t isqrt_small(uint32_t q) {
 }
 
 // bit k of the result = byte k of x is non-zero
+// byte b of the result = 1 if byte b of x is non-zero, else 0
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
+    const uint32_t t = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x;  // bit 7 of each byte = byte != 0
+    return (t >> 7) & 0x01010101u;
+}
+// bit b of the result = byte b of x is non-zero (a byte-wise dot product with 1, 2, 4, 8 gathers the flags)
 __device__ __forceinline__ uint32_t nonzero4(uint32_t x) {
-    uint32_t t = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x;  // bit 7 of each byte = byte != 0
-    t = (t >> 7) & 0x01010101u;
-    return (t * 0x10204080u) >> 28;
+    return __builtin_amdgcn_udot4(nonzero_bytes(x), 0x08040201u, 0u, false);
+}
+// the same for 16 bytes: bit 4 * w + b = byte b of x[w] is non-zero
+__device__ __forceinline__ uint32_t nonzero16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+    const uint32_t lo = __builtin_amdgcn_udot4(nonzero_bytes(x1), 0x80402010u, nonzero4(x0), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(nonzero_bytes(x3), 0x80402010u, nonzero4(x2), false);
+    return lo | (hi << 8);
 }
 // 4 bits -> 4 bytes of 0x00 / 0xff
 __device__ __forceinline__ uint32_t spread4(uint32_t bits4) {

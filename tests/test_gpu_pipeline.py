@@ -75,6 +75,19 @@ CHAINS = {
         {"type": O.OP_THRESHOLD, "iparam": 120}, {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": ONES9},
         {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": [1, 0, 0, 0, 1, 0, 0, 0, 1]},
         {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": [0, 0, 1, 1, 1, 1, 1, 0, 0]}],
+    # runs of 3x3 erosions / dilations (one bit-mask pass for up to three of them)
+    "erode3x": [{"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": CROSS},
+                {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": [1, 0, 0, 0, 1, 1, 0, 0, 0]},
+                {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": [0, 0, 0, 0, 0, 0, 0, 1, 1]}],
+    "morph-mix": [{"type": O.OP_THRESHOLD, "iparam": 150}, {"type": O.OP_SOBEL},
+                  {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": [1, 1, 0, 0, 0, 0, 0, 0, 1]},
+                  {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": [0, 0, 1, 0, 0, 0, 1, 0, 0]},
+                  {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": ONES9},
+                  {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": CROSS},
+                  {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": ONES9}],
+    "open-close": [{"type": O.OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": ONES9},
+                   {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": [0, 1, 0, 0, 1, 0, 0, 0, 0]},
+                   {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": [0, 1, 0, 0, 1, 0, 0, 0, 0]}],
     "linears": [{"type": O.OP_LINEAR, "kW": 3, "kH": 3, "fkernel": [1, 1, 1, 10, 1, 1, 1, 1, 1]},
                 {"type": O.OP_AVERAGE, "kW": 3, "kH": 3, "fkernel": [0.5, 0.25, 0.5, 1, 2, 1, 0.5, 0.25, 0.5]},
                 {"type": O.OP_LINEAR, "kW": 3, "kH": 3, "fkernel": [0.3, -0.2, 0.1, 0.7, 1.1, -0.4, 0.25, 0.05, 0.6]},
@@ -96,7 +109,7 @@ def Pipeline():
 @pytest.mark.parametrize("name", list(CHAINS))
 @pytest.mark.parametrize("fused", [False, "pointwise", True, "strips"])
 @pytest.mark.parametrize("W,H,kind", [(64, 48, "C"), (37, 23, "U"), (768, 40, "C"), (48, 203, "U"), (1056, 21, "U"),
-                                      (16, 9, "U"), (2048, 5, "C")])
+                                      (16, 9, "U"), (2048, 5, "C"), (8, 11, "U")])
 def test_pipeline_matches_oracle(Pipeline, name, fused, W, H, kind):
     ops = CHAINS[name]
     B = 3
