@@ -1,17 +1,10 @@
 // The kernel that runs a chain of per-pixel operations and the 3x3 stencil behind it in one
-// pass, staging the chain's output in LDS.  Shared by the pipeline executor and the feature
-// extraction entry point.
+// pass, staging the chain's output in LDS.
 #pragma once
 #include "iak_chain.hpp"
 #include "iak_stencil_ops.hpp"
 
 namespace iak {
-
-// number of bytes of x equal to 0xff
-__device__ __forceinline__ uint32_t bytes_equal_255(uint32_t x) {
-    const uint32_t m = x & 0x80808080u & ((x & 0x7f7f7f7fu) + 0x01010101u);
-    return (uint32_t)__builtin_popcount(m);
-}
 
 // ---------------------------------------------------------------------------------------
 // Chain fused into the following 3x3 stencil.  A workgroup stages a tile of the CHAIN'S OUTPUT
@@ -23,14 +16,11 @@ __device__ __forceinline__ uint32_t bytes_equal_255(uint32_t x) {
 // chain(0).
 // ---------------------------------------------------------------------------------------
 #define CS_THREADS 512
-// COUNT255: nothing is stored; the workgroup adds the number of output pixels equal to 255 to
-// counts[b] (the "perimeter" of imageMachineLearning.cu:362-366 without writing the edge image).
-template <class Op, bool COUNT255 = false>
+template <class Op>
 __global__ __launch_bounds__(CS_THREADS) void chain_stencil8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                              int W, int H, long long in_stride, long long out_stride,
                                                              ChainDesc d, const uint16_t *__restrict__ tables, int TW,
-                                                             int TH, int tiles_x, Op op,
-                                                             uint32_t *__restrict__ counts = nullptr) {
+                                                             int TH, int tiles_x, Op op) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int pitch = TW + 32;
     const int tile_bytes = (TH + 2) * pitch;
@@ -80,7 +70,6 @@ __global__ __launch_bounds__(CS_THREADS) void chain_stencil8_kernel(const uint8_
     // phase 2: the stencil on 8-pixel chunks x groups of 8 rows, rows coming from the tile
     const int cols = TW >> 3;
     const int items = cols * (TH >> 3);
-    uint32_t n255 = 0;
     for (int it = threadIdx.x; it < items; it += CS_THREADS) {
         const int rg = it / cols, cx = it - rg * cols;
         const int col0 = x0 + (cx << 3);
@@ -106,18 +95,10 @@ __global__ __launch_bounds__(CS_THREADS) void chain_stencil8_kernel(const uint8_
                 if (row < 1) o[0] = o[1] = 0;
                 if (col0 == 0) o[0] &= 0xffffff00u;
             }
-            if (COUNT255) {
-                if (row < H) n255 += bytes_equal_255(o[0]) + bytes_equal_255(o[1]);
-            } else {
-                if (row < H) st8<IAK_NT_STENCIL_ST>(dst + (long long)row * W + col0, o[0], o[1]);
-            }
+            if (row < H) st8<IAK_NT_STENCIL_ST>(dst + (long long)row * W + col0, o[0], o[1]);
             up = mid;
             mid = dn;
         }
-    }
-    if (COUNT255) {
-        for (int o = 32; o > 0; o >>= 1) n255 += __shfl_down(n255, o);
-        if ((threadIdx.x & 63) == 0 && n255) atomicAdd(&counts[b], n255);
     }
 }
 
@@ -149,16 +130,15 @@ static TileGeom tile_geometry(int W, int H) {
     return g;
 }
 
-// in: B images at stride in_stride, 16-byte aligned; W % 16 == 0; out 8-byte aligned (or, with
-// COUNT255, counts[B] zeroed by the caller).  tables: [B][CHAIN_MAX][256] as chain_prep_kernel
-// or any other producer lays them out.
-template <class Op, bool COUNT255 = false>
+// in: B images at stride in_stride, 16-byte aligned; W % 16 == 0; out 8-byte aligned.
+// tables: [B][CHAIN_MAX][256] as chain_prep_kernel lays them out.
+template <class Op>
 static int launch_chain_stencil(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
                                 long long out_stride, const ChainDesc &d, const uint16_t *tables, const Op &op,
-                                hipStream_t s, uint32_t *counts = nullptr) {
+                                hipStream_t s) {
     const TileGeom g = tile_geometry(W, H);
-    hipLaunchKernelGGL((chain_stencil8_kernel<Op, COUNT255>), dim3(g.tiles_x * g.tiles_y, B), dim3(CS_THREADS), g.lds, s, in,
-                       out, W, H, in_stride, out_stride, d, tables, g.TW, g.TH, g.tiles_x, op, counts);
+    hipLaunchKernelGGL((chain_stencil8_kernel<Op>), dim3(g.tiles_x * g.tiles_y, B), dim3(CS_THREADS), g.lds, s, in, out, W, H,
+                       in_stride, out_stride, d, tables, g.TW, g.TH, g.tiles_x, op);
     IAK_LAUNCH_CHECK();
     return 0;
 }

@@ -4,8 +4,9 @@
 // (statistics, Otsu threshold, histogram of the mask, compass filter, histogram of the edges,
 // histogram of the image).  Everything but the edge count is a function of the image's
 // 256-bin histogram; the edge count needs the compass filter of the Otsu mask, which is
-// computed here straight from the image (mask staged in LDS) and counted without being stored:
-// one histogram pass (skipped when the caller has the histogram) plus one read of the image.
+// computed here straight from the image on bit masks (one bit per mask pixel, the filter as a
+// 512-entry table) and counted without being stored: one histogram pass (skipped when the
+// caller has the histogram) plus one read of the image.
 //
 // kMeansThresholding (imageAnalysis.cu:281-379): a pixel's label depends on its value only,
 // so each iteration's class sums and counts come from the histogram; the image is touched by
@@ -66,6 +67,101 @@ __global__ void features_perimeter_kernel(const uint32_t *__restrict__ counts, c
                                           float *__restrict__ features, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) features[(long long)b * FEAT_N + 3] = (float)(int)(counts ? counts[b] : edge_hist[(long long)b * 256 + 255]);
+}
+
+// ---- the edge count on bit masks -----------------------------------------------------------
+// The compass filter runs on the Otsu mask, whose pixels are 0 or 255, so its output at a pixel
+// is a function of the nine mask bits around it.  kCompass255[idx] says whether that output is
+// 255 (idx bit 3 * i + j = mask pixel at row offset i - 1, column offset j - 1), evaluated once on
+// the host with the filter's own arithmetic (imageAnalysis.cu:592-639: four masks, the running
+// sum carried from mask to mask, the largest |sum| seen, low byte).
+struct CompassLut {
+    uint8_t is255[512];
+};
+static CompassLut make_compass_lut() {
+    CompassLut t;
+    for (int idx = 0; idx < 512; idx++) {
+        int p[9];
+        for (int n = 0; n < 9; n++) p[n] = ((idx >> n) & 1) * 255;
+        const int s0 = -p[0] + p[2] - 2 * p[3] + 2 * p[5] - p[6] + p[8];
+        const int s1 = -2 * p[0] - p[1] - p[3] + p[5] + p[7] + 2 * p[8];
+        const int s2 = -p[0] - 2 * p[1] - p[2] + p[6] + 2 * p[7] + p[8];
+        const int s3 = -p[1] - 2 * p[2] + p[3] - p[5] + 2 * p[6] + p[7];
+        int sum = s0 < 0 ? -s0 : s0, mx = sum;
+        sum += s1; sum = sum < 0 ? -sum : sum; mx = sum > mx ? sum : mx;
+        sum += s2; sum = sum < 0 ? -sum : sum; mx = sum > mx ? sum : mx;
+        sum += s3; sum = sum < 0 ? -sum : sum; mx = sum > mx ? sum : mx;
+        t.is255[idx] = (mx & 0xff) == 255 ? 1 : 0;
+    }
+    return t;
+}
+
+// byte b of the result = 1 if byte b of x is greater than t, with kw = (255 - t) in every byte:
+// the carry out of the byte-wise sum x + kw
+__device__ __forceinline__ uint32_t bytes_above(uint32_t x, uint32_t kw) {
+    const uint32_t lo = (x & 0x7f7f7f7fu) + (kw & 0x7f7f7f7fu);
+    const uint32_t carry = (x & kw) | ((x | kw) & lo);
+    return (carry >> 7) & 0x01010101u;
+}
+
+// counts[b] += number of pixels whose compass response on the mask (pixel > thr[b]) is 255.
+// A lane owns 8 pixels x 8 rows: ten 16-byte loads, ten 10-bit mask rows, one table look-up
+// per pixel.  Flat view of the image as everywhere: the pixel right of a row's last one is the
+// next row's first, pixels outside the image are 0 (never above a threshold >= 0), and the
+// filter's border (row 0, column 0) is not counted.  W % 8 == 0, images 4-byte aligned.
+__global__ __launch_bounds__(256) void perimeter_bits_kernel(const uint8_t *__restrict__ in, int W, int H, long long stride,
+                                                             const int32_t *__restrict__ thr, uint32_t *__restrict__ counts,
+                                                             CompassLut lut) {
+    __shared__ uint8_t table[512];
+    for (int i = threadIdx.x; i < 512; i += 256) table[i] = lut.is255[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const uint8_t *src = in + (long long)b * stride;
+    const int N = W * H;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
+    const uint32_t kw = (uint32_t)(255 - thr[b]) * 0x01010101u;
+    const int chunks = W >> 3;
+    const int items = chunks * ((H + 7) >> 3);
+    uint32_t n255 = 0;
+    for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < items; it += gridDim.x * blockDim.x) {
+        const int strip = it / chunks;
+        const int col0 = (it - strip * chunks) << 3;
+        const int y0 = strip << 3;
+        uint32_t bits[10];  // bit i of row r = mask pixel (y0 - 1 + r, col0 - 1 + i)
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            const int voff = (y0 - 1 + r) * W + col0 - 4;
+            // a negative offset is out of range as unsigned (row -1 is never looked at by a counted
+            // pixel); the clamp keeps the compiler from splitting the offset into register + immediate
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)min((uint32_t)voff, (uint32_t)N), 0, 0);
+            if (voff == -4) {  // first chunk of the image: only the four bytes in front of it are out of range
+                const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, 0, 0);
+                v[0] = 0; v[1] = f[0]; v[2] = f[1]; v[3] = f[2];
+            }
+            const uint32_t lo = __builtin_amdgcn_udot4(bytes_above(v[1], kw), 0x80402010u,
+                                                       __builtin_amdgcn_udot4(bytes_above(v[0], kw), 0x08040201u, 0u, false), false);
+            const uint32_t hi = __builtin_amdgcn_udot4(bytes_above(v[3], kw), 0x80402010u,
+                                                       __builtin_amdgcn_udot4(bytes_above(v[2], kw), 0x08040201u, 0u, false), false);
+            bits[r] = ((lo | (hi << 8)) >> 3) & 0x3ffu;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int row = y0 + r;
+            // the three 10-bit rows side by side; rows that are not counted look at nothing
+            uint32_t c = bits[r] | (bits[r + 1] << 10) | (bits[r + 2] << 20);
+            if (row < 1 || row >= H) c = 0;  // index 0: no response
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint32_t t = c >> j;
+                if (j == 0 && col0 == 0) t = 0;  // column 0 is border
+                // bits 0-2, 10-12, 20-22 -> one 9-bit index (the three partial products do not overlap)
+                const uint32_t idx = (__umul24(t & 0x00701c07u, 0x4081u) >> 14) & 0x1ffu;
+                n255 += table[idx];
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) n255 += __shfl_down(n255, o);
+    if ((threadIdx.x & 63) == 0 && n255) atomicAdd(&counts[b], n255);
 }
 
 // ---- kMeansThresholding (imageAnalysis.cu:281-379), k = 2, on the histogram ------------------
@@ -284,12 +380,11 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
     if (W % 16 == 0 && N < (1LL << 30)) {
         // the workspace for this shape holds no image buffers: the one-pass form is the only one
         if (!aligned16(img) || stride % 16 != 0) return IAK_E_UNSUPPORTED;
-        ChainDesc d;
-        memset(&d, 0, sizeof d);
-        d.n = 1;
-        d.st[0].type = C_OTSU;
-        if ((rc = launch_chain_stencil<Compass8, true>(img, nullptr, W, H, B, stride, 0, d, tables, Compass8(), s, counts)))
-            return rc;
+        static const CompassLut lut = make_compass_lut();
+        const long long items = (long long)(W >> 3) * ((H + 7) / 8);
+        hipLaunchKernelGGL(perimeter_bits_kernel, dim3(blocks_x(items, 256, B, 1 << 20), B), dim3(256), 0, s, img, W, H, stride,
+                           thr, counts, lut);
+        IAK_LAUNCH_CHECK();
         hipLaunchKernelGGL(features_perimeter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, counts, (const uint32_t *)nullptr,
                            features, B);
     } else {
