@@ -12,6 +12,7 @@
 // so each iteration's class sums and counts come from the histogram; the image is touched by
 // one table pass at the end.
 #include "iak_block.hpp"
+#include "iak_bitmask.hpp"
 #include "iak_chain_stencil.hpp"
 #include "iak_device_fns.hpp"
 #include "iak_common.hpp"
@@ -96,14 +97,6 @@ static CompassLut make_compass_lut() {
     return t;
 }
 
-// byte b of the result = 1 if byte b of x is greater than t, with kw = (255 - t) in every byte:
-// the carry out of the byte-wise sum x + kw
-__device__ __forceinline__ uint32_t bytes_above(uint32_t x, uint32_t kw) {
-    const uint32_t lo = (x & 0x7f7f7f7fu) + (kw & 0x7f7f7f7fu);
-    const uint32_t carry = (x & kw) | ((x | kw) & lo);
-    return (carry >> 7) & 0x01010101u;
-}
-
 // counts[b] += number of pixels whose compass response on the mask (pixel > thr[b]) is 255.
 // A lane owns 8 pixels x 8 rows: ten 16-byte loads, ten 10-bit mask rows, one table look-up
 // per pixel.  Flat view of the image as everywhere: the pixel right of a row's last one is the
@@ -129,21 +122,7 @@ __global__ __launch_bounds__(256) void perimeter_bits_kernel(const uint8_t *__re
         const int y0 = strip << 3;
         uint32_t bits[10];  // bit i of row r = mask pixel (y0 - 1 + r, col0 - 1 + i)
 #pragma unroll
-        for (int r = 0; r < 10; r++) {
-            const int voff = (y0 - 1 + r) * W + col0 - 4;
-            // a negative offset is out of range as unsigned (row -1 is never looked at by a counted
-            // pixel); the clamp keeps the compiler from splitting the offset into register + immediate
-            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)min((uint32_t)voff, (uint32_t)N), 0, 0);
-            if (voff == -4) {  // first chunk of the image: only the four bytes in front of it are out of range
-                const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, 0, 0);
-                v[0] = 0; v[1] = f[0]; v[2] = f[1]; v[3] = f[2];
-            }
-            const uint32_t lo = __builtin_amdgcn_udot4(bytes_above(v[1], kw), 0x80402010u,
-                                                       __builtin_amdgcn_udot4(bytes_above(v[0], kw), 0x08040201u, 0u, false), false);
-            const uint32_t hi = __builtin_amdgcn_udot4(bytes_above(v[3], kw), 0x80402010u,
-                                                       __builtin_amdgcn_udot4(bytes_above(v[2], kw), 0x08040201u, 0u, false), false);
-            bits[r] = ((lo | (hi << 8)) >> 3) & 0x3ffu;
-        }
+        for (int r = 0; r < 10; r++) bits[r] = mask_row10(rsrc, (y0 - 1 + r) * W + col0 - 4, N, kw);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int row = y0 + r;
@@ -152,11 +131,8 @@ __global__ __launch_bounds__(256) void perimeter_bits_kernel(const uint8_t *__re
             if (row < 1 || row >= H) c = 0;  // index 0: no response
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                uint32_t t = c >> j;
-                if (j == 0 && col0 == 0) t = 0;  // column 0 is border
-                // bits 0-2, 10-12, 20-22 -> one 9-bit index (the three partial products do not overlap)
-                const uint32_t idx = (__umul24(t & 0x00701c07u, 0x4081u) >> 14) & 0x1ffu;
-                n255 += table[idx];
+                const uint32_t hit = table[nine_bits(c, j)];
+                n255 += (j == 0 && col0 == 0) ? 0u : hit;  // column 0 is border
             }
         }
     }

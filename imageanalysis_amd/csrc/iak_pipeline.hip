@@ -16,6 +16,7 @@
 #include "iak_chain.hpp"
 #include "iak_hist.hpp"
 #include "iak_chain_stencil.hpp"
+#include "iak_binary_stencil.hpp"
 #include "iak_strip.hpp"
 #include "iak_stencil_ops.hpp"
 
@@ -222,6 +223,8 @@ struct Group {
     bool chain_needs_hist = false;
     StripDesc strip;      // G_STRIP
     bool emit_hist = false;  // G_CHAIN, G_OP: the pass also leaves the histogram of its output
+    bool binary = false;     // G_CHAIN_OP: the run is one threshold, the stencil is done by table (bt)
+    BinTable bt;
 };
 
 // operators the fused chain+stencil kernel can take over (the 8-pixel 3x3 family)
@@ -355,6 +358,34 @@ static int take_strip(const iak_pipeline *p, int i, Group *g) {
     return run;
 }
 
+// The 512 results of a 3x3 operation on 0 / 255 pixels, from the operation's own kernel run once
+// on the image of all patterns (synchronous; pipeline creation only).
+static int eval_binary_table(const iak_op &o, BinTable *bt) {
+    std::vector<uint8_t> host((size_t)BT_W * BT_H, 0);
+    binary_patterns_image(host.data());
+    const long long n = (long long)BT_W * BT_H;
+    uint8_t *din = nullptr, *dout = nullptr;
+    int rc = (int)hipMalloc((void **)&din, (size_t)n);
+    if (rc == 0) rc = (int)hipMalloc((void **)&dout, (size_t)n);
+    if (rc == 0) rc = (int)hipMemcpy(din, host.data(), (size_t)n, hipMemcpyHostToDevice);
+    if (rc == 0) {
+        switch (o.type) {
+        case IAK_OP_LINEAR: rc = iak_linear(din, dout, BT_W, BT_H, 1, n, n, o.fkernel, 3, 3, IAK_LINEAR_CLAMP, nullptr); break;
+        case IAK_OP_AVERAGE: rc = iak_linear(din, dout, BT_W, BT_H, 1, n, n, o.fkernel, 3, 3, IAK_LINEAR_AVERAGE, nullptr); break;
+        case IAK_OP_MEDIAN: rc = iak_median(din, dout, BT_W, BT_H, 1, n, n, o.ikernel, 3, 3, nullptr); break;
+        case IAK_OP_SOBEL: rc = iak_sobel(din, dout, BT_W, BT_H, 1, n, n, nullptr); break;
+        case IAK_OP_COMPASS: rc = iak_compass(din, dout, BT_W, BT_H, 1, n, n, nullptr); break;
+        case IAK_OP_ERODE: rc = iak_erode(din, dout, BT_W, BT_H, 1, n, n, o.ikernel, 3, 3, nullptr); break;
+        default: rc = IAK_E_UNSUPPORTED; break;
+        }
+    }
+    if (rc == 0) rc = (int)hipMemcpy(host.data(), dout, (size_t)n, hipMemcpyDeviceToHost);
+    if (rc == 0) binary_table_from_output(host.data(), bt);
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    return rc;
+}
+
 static int plan(iak_pipeline *p) {
     p->groups.clear();
     Group g0;
@@ -446,6 +477,11 @@ static int plan(iak_pipeline *p) {
             if ((p->mode == IAK_PIPE_FUSED || p->mode == IAK_PIPE_FUSED_STRIPS) && i < n && p->W % 16 == 0 && (long long)p->W * p->H < (1LL << 30) && is_fusable_stencil(p->ops[i].op)) {
                 g.kind = G_CHAIN_OP;
                 g.op_index = i;
+                // one threshold (fixed and not negative, or Otsu) in front of an operation that zeroes
+                // its border: the operation becomes a look-up in a table of its 512 possible results
+                const iak_op &th = p->ops[i - 1].op;
+                g.binary = g.chain.n == 1 && p->ops[i].op.type != IAK_OP_DILATE &&
+                           (th.type == IAK_OP_OTSU || (th.type == IAK_OP_THRESHOLD && th.iparam >= 0));
                 g.alg_bytes += op_alg_bytes(p->ops[i].op.type);
                 g.name += std::string("+") + op_name(p->ops[i].op.type);
                 i++;
@@ -626,6 +662,8 @@ int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op
     }
 #undef TRY
     int rc = plan(p);
+    for (auto &g : p->groups)
+        if (rc == 0 && g.kind == G_CHAIN_OP && g.binary) rc = eval_binary_table(p->ops[g.op_index].op, &g.bt);
     if (rc != 0) { free_all(p); delete p; return rc; }
     *out = p;
     return 0;
@@ -870,6 +908,11 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
                 IAK_HIP(hipEventRecord(ev[2 * gi + 1], s));
             }
             const iak_op &o = p->ops[g.op_index].op;
+            if (g.binary) {
+                rc = launch_binary_table_stencil(cur, dst, p->W, p->H, B, N, N, sl.tables, g.bt, s);
+                cur_hist = nullptr;
+                break;
+            }
             auto go = [&](const auto &op) {
                 return launch_chain_stencil(cur, dst, p->W, p->H, B, N, N, cd, sl.tables, op, s);
             };

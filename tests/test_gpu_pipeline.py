@@ -88,6 +88,16 @@ CHAINS = {
     "open-close": [{"type": O.OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": ONES9},
                    {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": [0, 1, 0, 0, 1, 0, 0, 0, 0]},
                    {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": [0, 1, 0, 0, 1, 0, 0, 0, 0]}],
+    # one threshold in front of each border-zeroing 3x3 operation (done by table on the mask bits)
+    "thresholded-stencils": [
+        {"type": O.OP_THRESHOLD, "iparam": 100},
+        {"type": O.OP_LINEAR, "kW": 3, "kH": 3, "fkernel": [0.3, -0.2, 0.1, 0.7, 0.11, -0.4, 0.25, 0.05, 0.06]},
+        {"type": O.OP_THRESHOLD, "iparam": 50}, {"type": O.OP_AVERAGE, "kW": 3, "kH": 3, "fkernel": [0.5, 0.25, 0.5, 1, 2, 1, 0.5, 0.25, 0.5]},
+        {"type": O.OP_OTSU}, {"type": O.OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": ONES9},
+        {"type": O.OP_THRESHOLD, "iparam": 0}, {"type": O.OP_COMPASS},
+        {"type": O.OP_THRESHOLD, "iparam": 254}, {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": CROSS},
+        {"type": O.OP_THRESHOLD, "iparam": 255}, {"type": O.OP_SOBEL},
+        {"type": O.OP_THRESHOLD, "iparam": -1}, {"type": O.OP_SOBEL}],
     "linears": [{"type": O.OP_LINEAR, "kW": 3, "kH": 3, "fkernel": [1, 1, 1, 10, 1, 1, 1, 1, 1]},
                 {"type": O.OP_AVERAGE, "kW": 3, "kH": 3, "fkernel": [0.5, 0.25, 0.5, 1, 2, 1, 0.5, 0.25, 0.5]},
                 {"type": O.OP_LINEAR, "kW": 3, "kH": 3, "fkernel": [0.3, -0.2, 0.1, 0.7, 1.1, -0.4, 0.25, 0.05, 0.6]},
