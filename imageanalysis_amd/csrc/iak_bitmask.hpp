@@ -14,6 +14,16 @@ __device__ __forceinline__ uint32_t bytes_above(uint32_t x, uint32_t kw) {
     return (carry >> 7) & 0x01010101u;
 }
 
+// bit 4 * w + b of the result = byte b of x[w] is above the threshold (byte-wise dot products
+// with 1, 2, 4, ... gather the flags)
+__device__ __forceinline__ uint32_t above16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t kw) {
+    const uint32_t lo = __builtin_amdgcn_udot4(bytes_above(x1, kw), 0x80402010u,
+                                               __builtin_amdgcn_udot4(bytes_above(x0, kw), 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(bytes_above(x3, kw), 0x80402010u,
+                                               __builtin_amdgcn_udot4(bytes_above(x2, kw), 0x08040201u, 0u, false), false);
+    return lo | (hi << 8);
+}
+
 // One 16-byte row load (columns col0-4 .. col0+11 at flat offset voff + 4) as 10 mask bits:
 // bit i = pixel col0 - 1 + i is above the threshold.
 __device__ __forceinline__ uint32_t mask_row10(__amdgpu_buffer_rsrc_t rsrc, int voff, int N, uint32_t kw) {
@@ -24,11 +34,7 @@ __device__ __forceinline__ uint32_t mask_row10(__amdgpu_buffer_rsrc_t rsrc, int 
         const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, 0, 0);
         v[0] = 0; v[1] = f[0]; v[2] = f[1]; v[3] = f[2];
     }
-    const uint32_t lo = __builtin_amdgcn_udot4(bytes_above(v[1], kw), 0x80402010u,
-                                               __builtin_amdgcn_udot4(bytes_above(v[0], kw), 0x08040201u, 0u, false), false);
-    const uint32_t hi = __builtin_amdgcn_udot4(bytes_above(v[3], kw), 0x80402010u,
-                                               __builtin_amdgcn_udot4(bytes_above(v[2], kw), 0x08040201u, 0u, false), false);
-    return ((lo | (hi << 8)) >> 3) & 0x3ffu;
+    return (above16(v[0], v[1], v[2], v[3], kw) >> 3) & 0x3ffu;
 }
 
 // the 9-bit table index of pixel j of a row from the three 10-bit rows packed side by side

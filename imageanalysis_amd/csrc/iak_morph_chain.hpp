@@ -16,6 +16,8 @@
 //   dilation: out = OR over set elements of the source at the mirrored offset; sources are the
 //             set pixels that are not on the border; nothing outside the image.
 #pragma once
+#include "iak_bitmask.hpp"
+#include "iak_chain.hpp"
 #include "iak_common.hpp"
 #include "iak_hist.hpp"
 #include "iak_stencil_ops.hpp"
@@ -24,7 +26,7 @@ namespace iak {
 
 #define MC_MAX_OPS 3
 struct MorphChainDesc {
-    int n;                     // 2 or 3 stages
+    int n;                     // 1 to 3 stages (1 only behind a threshold)
     uint32_t mask[MC_MAX_OPS];   // bit e: structuring element e (row-major) is non-zero
     uint8_t dilate[MC_MAX_OPS];  // stage is a dilation (else an erosion)
 };
@@ -118,10 +120,14 @@ __device__ __forceinline__ void mc_stages(uint32_t (&bits)[8 + 2 * NOPS], const 
 // HIST: 0 no histogram; 1 the output's histogram through the LDS table (runs of erosions: grey
 // values); 2 the output is 0 / 255 (a dilation has been passed), so its histogram is the number
 // of set bits, added to bin 255 (bin 0 is never counted, imageAnalysis.cu:130-152).
-template <int NOPS, int HIST>
+// THR: the run works on the image thresholded first (pixel > t ? 255 : 0, t >= 0): the bit of a
+// pixel is "above t" instead of "non-zero", t read off slot 0 of the image's tables (laid out
+// [B][CHAIN_MAX][256] by the table prologue: 0 up to t, 255 above), and the output is 0 / 255.
+template <int NOPS, int HIST, bool THR>
 __global__ __launch_bounds__(256) void morph_chain_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
                                                           int H, long long in_stride, long long out_stride,
-                                                          MorphChainDesc d, uint32_t *__restrict__ hist) {
+                                                          MorphChainDesc d, uint32_t *__restrict__ hist,
+                                                          const uint16_t *__restrict__ tables) {
     __shared__ uint32_t sh[HIST == 1 ? 256 * HIST_COLS : 1];
     if (HIST == 1) hist_zero(sh);
     uint32_t n255 = 0;
@@ -133,9 +139,11 @@ __global__ __launch_bounds__(256) void morph_chain_kernel(const uint8_t *__restr
     const int chunks = W >> 3;
     const int strips = (H + 7) >> 3;
     const int items = chunks * strips;
-    bool binary = false;  // a dilation has been passed: values are 0 / 255
+    bool binary = THR;  // a threshold or a dilation has been passed: values are 0 / 255
 #pragma unroll
     for (int s = 0; s < NOPS; s++) binary = binary || d.dilate[s];
+    uint32_t kw = 0;  // 255 - t in every byte
+    if (THR) kw = (uint32_t)__syncthreads_count((tables[(long long)blockIdx.y * CHAIN_MAX * 256 + threadIdx.x] & 0xffu) != 0) * 0x01010101u;
     for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < items; it += gridDim.x * blockDim.x) {
         const int strip = it / chunks;
         const int cx = it - strip * chunks;
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void morph_chain_kernel(const uint8_t *__restr
                 const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, 0, 0);
                 v[0] = 0; v[1] = f[0]; v[2] = f[1]; v[3] = f[2];
             }
-            const uint32_t m16 = nonzero16(v[0], v[1], v[2], v[3]);
+            const uint32_t m16 = THR ? above16(v[0], v[1], v[2], v[3], kw) : nonzero16(v[0], v[1], v[2], v[3]);
             bits[r] = (m16 >> (4 - NOPS)) & ((1u << (8 + 2 * NOPS)) - 1u);  // bit i = pixel col0 - NOPS + i
             if (r >= NOPS && r < NOPS + 8) {
                 keep[r - NOPS][0] = v[1];
@@ -197,21 +205,27 @@ static bool morph_chain_ok(const uint8_t *in, const uint8_t *out, int W, int H, 
            reinterpret_cast<uintptr_t>(out) % 8 == 0 && in_stride % 4 == 0 && out_stride % 8 == 0;
 }
 
+// tables: null, or the per-image tables whose slot 0 is the threshold in front of the run
 static int launch_morph_chain(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
-                              const MorphChainDesc &d, uint32_t *hist, hipStream_t s) {
-    if (d.n < 2 || d.n > MC_MAX_OPS || !morph_chain_ok(in, out, W, H, in_stride, out_stride)) return IAK_E_UNSUPPORTED;
+                              const MorphChainDesc &d, uint32_t *hist, const uint16_t *tables, hipStream_t s) {
+    if (d.n < (tables ? 1 : 2) || d.n > MC_MAX_OPS || !morph_chain_ok(in, out, W, H, in_stride, out_stride)) return IAK_E_UNSUPPORTED;
     const long long items = (long long)(W >> 3) * ((H + 7) / 8);
     if (hist) IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
-    bool binary = false;
+    bool binary = tables != nullptr;
     for (int k = 0; k < d.n; k++) binary = binary || d.dilate[k];
     const int hmode = !hist ? 0 : (binary ? 2 : 1);
     const dim3 grid(blocks_x(items, 256, B, hmode == 1 ? 4096 : 1 << 20), B);
-#define MC_LAUNCH(NOPS, HIST) \
-    hipLaunchKernelGGL((morph_chain_kernel<NOPS, HIST>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, d, hist)
-    if (d.n == 2) {
-        if (hmode == 0) MC_LAUNCH(2, 0); else if (hmode == 1) MC_LAUNCH(2, 1); else MC_LAUNCH(2, 2);
+#define MC_LAUNCH(NOPS, HIST, THR)                                                                                      \
+    hipLaunchKernelGGL((morph_chain_kernel<NOPS, HIST, THR>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, d, \
+                       hist, tables)
+    if (tables) {
+        if (d.n == 1) { if (hmode) MC_LAUNCH(1, 2, true); else MC_LAUNCH(1, 0, true); }
+        else if (d.n == 2) { if (hmode) MC_LAUNCH(2, 2, true); else MC_LAUNCH(2, 0, true); }
+        else { if (hmode) MC_LAUNCH(3, 2, true); else MC_LAUNCH(3, 0, true); }
+    } else if (d.n == 2) {
+        if (hmode == 0) MC_LAUNCH(2, 0, false); else if (hmode == 1) MC_LAUNCH(2, 1, false); else MC_LAUNCH(2, 2, false);
     } else {
-        if (hmode == 0) MC_LAUNCH(3, 0); else if (hmode == 1) MC_LAUNCH(3, 1); else MC_LAUNCH(3, 2);
+        if (hmode == 0) MC_LAUNCH(3, 0, false); else if (hmode == 1) MC_LAUNCH(3, 1, false); else MC_LAUNCH(3, 2, false);
     }
 #undef MC_LAUNCH
     IAK_LAUNCH_CHECK();

@@ -196,7 +196,7 @@ namespace iak {
 int stencil3_with_hist(const iak_op &o, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
                        long long out_stride, uint32_t *hist, void *stream);  // iak_stencil.hip
 int morph_chain3(const iak_op *ops, int n, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
-                 long long out_stride, uint32_t *hist, void *stream);  // iak_stencil.hip
+                 long long out_stride, uint32_t *hist, const uint16_t *tables, void *stream);  // iak_stencil.hip
 }
 
 using namespace iak;
@@ -468,6 +468,27 @@ static int plan(iak_pipeline *p) {
                 gh.alg_bytes = 1;
                 p->groups.push_back(gh);
             }
+            // one threshold (fixed and not negative, or Otsu) in front of 3x3 erosions / dilations: the
+            // run works on "above the threshold" bits and the mask image is never written
+            auto is_morph3 = [&](int k) {
+                const iak_op &q = p->ops[k].op;
+                return (q.type == IAK_OP_ERODE || q.type == IAK_OP_DILATE) && q.kW == 3 && q.kH == 3;
+            };
+            const bool one_threshold = g.chain.n == 1 && (p->ops[i - 1].op.type == IAK_OP_OTSU ||
+                                                          (p->ops[i - 1].op.type == IAK_OP_THRESHOLD && p->ops[i - 1].op.iparam >= 0));
+            if ((p->mode == IAK_PIPE_FUSED || p->mode == IAK_PIPE_FUSED_STRIPS) && one_threshold && i < n && is_morph3(i) &&
+                p->W % 16 == 0 && (long long)p->W * ((long long)p->H + 8) < (1LL << 30)) {
+                int run = 0;
+                while (i + run < n && run < 3 && is_morph3(i + run)) run++;
+                g.kind = G_MORPH;
+                g.op_index = i;
+                g.n_ops = run;
+                for (int k = 0; k < run; k++) {
+                    g.alg_bytes += op_alg_bytes(p->ops[i + k].op.type);
+                    g.name += std::string("+") + op_name(p->ops[i + k].op.type);
+                }
+                i += run;
+            } else
             // a run of stencils right after the chain: one strip pass for the chain and all of them
             if (const int taken = take_strip(p, i, &g)) {
                 g.kind = G_STRIP;
@@ -961,8 +982,20 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
         case G_MORPH: {
             iak_op run[3];
             for (int k = 0; k < g.n_ops; k++) run[k] = p->ops[g.op_index + k].op;
-            rc = morph_chain3(run, g.n_ops, cur, dst, p->W, p->H, B, N, N, g.emit_hist ? sl.hist2 : nullptr, s);
-            if (rc == IAK_E_UNSUPPORTED && dst != sl.bufA && dst != sl.bufB && (cur == sl.bufA || cur == sl.bufB)) {
+            const uint16_t *thr_tables = nullptr;
+            if (g.chain.n) {  // the threshold in front of the run: its table first
+                const ChainDesc cd = chain_for(p, g.chain, b0);
+                if (cd.st[0].type == C_OTSU && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
+                hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables);
+                IAK_LAUNCH_CHECK();
+                if (ev) {
+                    p->split[gi] = 1;
+                    IAK_HIP(hipEventRecord(ev[2 * gi + 1], s));
+                }
+                thr_tables = sl.tables;
+            }
+            rc = morph_chain3(run, g.n_ops, cur, dst, p->W, p->H, B, N, N, g.emit_hist ? sl.hist2 : nullptr, thr_tables, s);
+            if (rc == IAK_E_UNSUPPORTED && !thr_tables && dst != sl.bufA && dst != sl.bufB && (cur == sl.bufA || cur == sl.bufB)) {
                 // the caller's output buffer is not aligned for the one-pass kernel: one operation
                 // at a time through the two intermediate buffers
                 const uint8_t *from = cur;

@@ -378,12 +378,14 @@ int stencil3_with_hist(const iak_op &o, const uint8_t *in, uint8_t *out, int W, 
     }
 }
 
-// A run of two or three 3x3 erosions / dilations as one pass (for the executor; not part of the C
-// ABI).  hist may be null.  IAK_E_UNSUPPORTED when the run or the buffers do not qualify.
+// A run of 3x3 erosions / dilations as one pass (for the executor; not part of the C ABI): two or
+// three of them, or one to three on the image thresholded first when `tables` is given (slot 0 of
+// each image's tables = the threshold's table).  hist may be null.  IAK_E_UNSUPPORTED when the
+// run or the buffers do not qualify.
 int morph_chain3(const iak_op *ops, int n, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
-                 long long out_stride, uint32_t *hist, void *stream) {
+                 long long out_stride, uint32_t *hist, const uint16_t *tables, void *stream) {
     if (check_image_args(in, out, W, H, B, in_stride, out_stride)) return IAK_E_ARG;
-    if (n < 2 || n > MC_MAX_OPS) return IAK_E_UNSUPPORTED;
+    if (n < (tables ? 1 : 2) || n > MC_MAX_OPS) return IAK_E_UNSUPPORTED;
     MorphChainDesc d;
     d.n = n;
     for (int k = 0; k < MC_MAX_OPS; k++) { d.mask[k] = 0; d.dilate[k] = 0; }
@@ -393,7 +395,7 @@ int morph_chain3(const iak_op *ops, int n, const uint8_t *in, uint8_t *out, int 
         d.mask[k] = se_mask3(o.ikernel);
         d.dilate[k] = o.type == IAK_OP_DILATE;
     }
-    return launch_morph_chain(in, out, W, H, B, in_stride, out_stride, d, hist, as_stream(stream));
+    return launch_morph_chain(in, out, W, H, B, in_stride, out_stride, d, hist, tables, as_stream(stream));
 }
 
 }  // namespace iak
