@@ -3,6 +3,7 @@
 // row's first pixel, taps outside [0, W*H) read 0), exactly like the one-pixel-per-lane
 // kernels they take over from.
 #pragma once
+#include "iak_box.hpp"
 #include "iak_common.hpp"
 #include "iak_stencil_ops.hpp"
 
@@ -159,6 +160,10 @@ static int launch_tiled_linear(const uint8_t *in, uint8_t *out, int W, int H, in
     if (mag * 255.0 >= 16777216.0) return IAK_E_UNSUPPORTED;  // sums must stay exact in float
     bool uniform = true;
     for (int i = 1; i < kWe * kHe; i++) uniform = uniform && t.f[i] == t.f[0];
+    if (uniform) {  // box filters whose per-tap truncation provably commutes with the sum: integer box sums
+        const int rc = launch_box_sum(in, out, W, H, B, in_stride, out_stride, kWe, kHe, t.f[0], divisor, avg, s);
+        if (rc != IAK_E_UNSUPPORTED) return rc;
+    }
 #define TL_CASE(K) case K: return launch_tiled_linear_kw<K>(in, out, W, H, B, in_stride, out_stride, kHe, divisor, avg, uniform, t, s);
     switch (kWe) {
         TL_CASE(1) TL_CASE(3) TL_CASE(5) TL_CASE(7) TL_CASE(9) TL_CASE(11) TL_CASE(13) TL_CASE(15) TL_CASE(17)

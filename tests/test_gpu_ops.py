@@ -268,6 +268,18 @@ def test_linear_tiled(ops, kW, kH, W, H, kind):
     each(lambda x: ops.averageFilter(x, huge, kW, kH), lambda x: O.average(x, huge, kW, kH), imgs)
 
 
+@pytest.mark.parametrize("w", [1.0 / 121, 1.0 / 25, 1.0, 0.5, 0.999, 1.0 / 3, 2.5, 3.7, 0.0078125, 1e-3])
+@pytest.mark.parametrize("kW,kH", [(11, 11), (5, 5), (25, 25), (7, 3), (1, 9), (4, 6)])
+@pytest.mark.parametrize("W,H,kind", [(200, 70, "C"), (131, 150, "U"), (64, 64, "K"), (9, 40, "U")])
+def test_box_filters(ops, w, kW, kH, W, H, kind):
+    # every tap the same weight: integer box sums where the per-tap truncation provably commutes
+    # with the sum, the tap-by-tap kernels otherwise (weights near an integer from below, big sums)
+    imgs = batch(kind, W, H, 2)
+    k = np.full(kW * kH, w, np.float32)
+    each(lambda x: ops.linearFilter(x, k, kW, kH), lambda x: O.linear(x, k, kW, kH), imgs)
+    each(lambda x: ops.averageFilter(x, k, kW, kH), lambda x: O.average(x, k, kW, kH), imgs)
+
+
 @pytest.mark.parametrize("kW,kH", [(5, 5), (7, 7), (15, 15), (3, 9), (9, 3), (1, 5), (5, 1), (15, 17)])
 @pytest.mark.parametrize("W,H,kind", [(200, 70, "C"), (131, 150, "U"), (64, 33, "K"), (300, 20, "C"), (5, 9, "U")])
 def test_median_sliding_histogram(ops, kW, kH, W, H, kind):
