@@ -6,6 +6,30 @@
 
 namespace iak {
 
+// 16 bytes of the image at flat offset voff (a multiple of 4, possibly negative or past the
+// end): bytes outside [0, N) read 0.  A wholly negative offset is out of range as unsigned; the
+// clamp keeps the compiler from splitting the offset into a negative register part and a
+// positive immediate (the range check is done on the unwrapped sum).  Only a load that
+// straddles offset 0 needs care: the range check would drop all of it, so its bytes are
+// fetched one by one.
+__device__ __forceinline__ u32x4 load16_flat(__amdgpu_buffer_rsrc_t rsrc, int voff, int N) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)min((uint32_t)voff, (uint32_t)N), 0, 0);
+    if (voff < 0 && voff > -16) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int o = voff + 4 * w + b;
+                const uint32_t byte = __builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)min((uint32_t)o, (uint32_t)N), 0, 0);
+                x |= (o < 0 ? 0u : byte) << (8 * b);
+            }
+            v[w] = x;
+        }
+    }
+    return v;
+}
+
 // byte b of the result = 1 if byte b of x is greater than t, with kw = (255 - t) in every byte:
 // the carry out of the byte-wise sum x + kw
 __device__ __forceinline__ uint32_t bytes_above(uint32_t x, uint32_t kw) {
@@ -27,13 +51,7 @@ __device__ __forceinline__ uint32_t above16(uint32_t x0, uint32_t x1, uint32_t x
 // One 16-byte row load (columns col0-4 .. col0+11 at flat offset voff + 4) as 10 mask bits:
 // bit i = pixel col0 - 1 + i is above the threshold.
 __device__ __forceinline__ uint32_t mask_row10(__amdgpu_buffer_rsrc_t rsrc, int voff, int N, uint32_t kw) {
-    // a negative offset is out of range as unsigned (such rows are never looked at by a pixel that
-    // counts); the clamp keeps the compiler from splitting the offset into register + immediate
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)min((uint32_t)voff, (uint32_t)N), 0, 0);
-    if (voff == -4) {  // first chunk of the image: only the four bytes in front of it are out of range
-        const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, 0, 0);
-        v[0] = 0; v[1] = f[0]; v[2] = f[1]; v[3] = f[2];
-    }
+    const u32x4 v = load16_flat(rsrc, voff, N);
     return (above16(v[0], v[1], v[2], v[3], kw) >> 3) & 0x3ffu;
 }
 

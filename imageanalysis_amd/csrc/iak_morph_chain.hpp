@@ -155,14 +155,9 @@ __global__ __launch_bounds__(256) void morph_chain_kernel(const uint8_t *__restr
 #pragma unroll
         for (int r = 0; r < R0; r++) {
             const int row = y0 - NOPS + r;
-            // A negative offset is out of range as unsigned, and row -1 .. -3 are never sources
-            // or surviving taps; the clamp keeps the compiler from splitting the offset.
-            const int voff = row * W + col0 - 4;
-            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)min((uint32_t)voff, (uint32_t)N), 0, 0);
-            if (voff == -4) {  // first chunk of the image: only the four bytes in front of it are out of range
-                const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, 0, 0);
-                v[0] = 0; v[1] = f[0]; v[2] = f[1]; v[3] = f[2];
-            }
+            // rows above the image read 0, but the last chunk of such a row runs on into row 0 on the
+            // flat view, and those pixels are taps of the next row's first pixels: load16_flat keeps them
+            const u32x4 v = load16_flat(rsrc, row * W + col0 - 4, N);
             const uint32_t m16 = THR ? above16(v[0], v[1], v[2], v[3], kw) : nonzero16(v[0], v[1], v[2], v[3]);
             bits[r] = (m16 >> (4 - NOPS)) & ((1u << (8 + 2 * NOPS)) - 1u);  // bit i = pixel col0 - NOPS + i
             if (r >= NOPS && r < NOPS + 8) {

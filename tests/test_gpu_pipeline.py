@@ -79,6 +79,10 @@ CHAINS = {
     "erode3x": [{"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": CROSS},
                 {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": [1, 0, 0, 0, 1, 1, 0, 0, 0]},
                 {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": [0, 0, 0, 0, 0, 0, 0, 1, 1]}],
+    # found by fuzzing: pixel (1, 1), as the halo of row 0's last chunk, takes a tap from pixel (0, 0)
+    "erode-dilate-erode": [{"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": [1, 0, 0, 0, 0, 0, 0, 1, 1]},
+                           {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": [0, 0, 0, 1, 0, 1, 1, 0, 0]},
+                           {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": [0, 0, 1, 1, 0, 0, 1, 0, 1]}],
     "morph-mix": [{"type": O.OP_THRESHOLD, "iparam": 150}, {"type": O.OP_SOBEL},
                   {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": [1, 1, 0, 0, 0, 0, 0, 0, 1]},
                   {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": [0, 0, 1, 0, 0, 0, 1, 0, 0]},
@@ -119,7 +123,7 @@ def Pipeline():
 @pytest.mark.parametrize("name", list(CHAINS))
 @pytest.mark.parametrize("fused", [False, "pointwise", True, "strips"])
 @pytest.mark.parametrize("W,H,kind", [(64, 48, "C"), (37, 23, "U"), (768, 40, "C"), (48, 203, "U"), (1056, 21, "U"),
-                                      (16, 9, "U"), (2048, 5, "C"), (8, 11, "U")])
+                                      (16, 9, "U"), (2048, 5, "C"), (8, 11, "U"), (40, 8, "C")])
 def test_pipeline_matches_oracle(Pipeline, name, fused, W, H, kind):
     ops = CHAINS[name]
     B = 3
