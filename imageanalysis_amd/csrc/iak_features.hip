@@ -355,7 +355,7 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
     IAK_LAUNCH_CHECK();
     if (W % 16 == 0 && N < (1LL << 30)) {
         // the workspace for this shape holds no image buffers: the one-pass form is the only one
-        if (!aligned16(img) || stride % 16 != 0) return IAK_E_UNSUPPORTED;
+        if ((reinterpret_cast<uintptr_t>(img) & 3u) || stride % 4 != 0) return IAK_E_UNSUPPORTED;
         static const CompassLut lut = make_compass_lut();
         const long long items = (long long)(W >> 3) * ((H + 7) / 8);
         hipLaunchKernelGGL(perimeter_bits_kernel, dim3(blocks_x(items, 256, B, 1 << 20), B), dim3(256), 0, s, img, W, H, stride,

@@ -179,7 +179,7 @@ int iak_erode(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in
  * mode (:341-351), rangeMin, rangeMax (:379-390; -1 for an all-zero image)}.  DEVICE float[B][7].
  * hist: the images' histograms [B][256] (bin 0 empty) if the caller has them, else NULL.
  * workspace: DEVICE memory of iak_features_workspace_bytes(W, H, B) bytes, 256-byte aligned.
- * W % 16 == 0 reads each image once and stores no image; it needs 16-byte aligned images and
+ * W % 16 == 0 reads each image once and stores no image; it needs 4-byte aligned images and
  * stride (IAK_E_UNSUPPORTED otherwise). */
 long long iak_features_workspace_bytes(int W, int H, int B);
 int iak_features(const uint8_t *img, int W, int H, int B, long long stride, const uint32_t *hist,
