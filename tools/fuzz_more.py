@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Extended differential fuzzing of the fused executor against the oracle, biased towards the
 threshold / morphology / 3x3-stencil runs that the bit-mask kernels take over.
-usage: python tools/fuzz_more.py [first_case] [n_cases]"""
+usage: python tools/fuzz_more.py [first_case] [n_cases] [big]   (big: images up to 1100 x 600)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,12 +15,16 @@ FOCUS = {O.OP_THRESHOLD, O.OP_OTSU, O.OP_DILATE, O.OP_ERODE, O.OP_SOBEL, O.OP_CO
          O.OP_AVERAGE, O.OP_FEATURES, O.OP_EQUALIZE}
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+big = len(sys.argv) > 3
 bad_cases = 0
 for case in range(first, first + count):
     rs = np.random.default_rng(case)
     W = int(rs.choice([8, 16, 24, 32, 40, 48, 64, 80, 96, 128, 136, 256])) if rs.random() < 0.75 else int(rs.integers(1, 90))
     H = int(rs.integers(1, 40))
-    B = int(rs.integers(1, 4))
+    if big:
+        W = int(rs.choice([256, 512, 768, 776, 1024, 1040, 1088])) if rs.random() < 0.75 else int(rs.integers(90, 1100))
+        H = int(rs.integers(40, 600))
+    B = int(rs.integers(1, 4)) if not big else int(rs.integers(1, 3))
     kind = str(rs.choice(["C", "U", "K"]))
     ops = []
     for _ in range(int(rs.integers(1, 8))):
@@ -50,7 +54,7 @@ for case in range(first, first + count):
         if bad_cases >= 5:
             break
     p.close()
-    if (case - first) % 200 == 0:
+    if (case - first) % (10 if big else 200) == 0:
         print("case", case, "ok so far", flush=True)
 print("done:", bad_cases, "bad cases of", count, flush=True)
 sys.exit(1 if bad_cases else 0)
