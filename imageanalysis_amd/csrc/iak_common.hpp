@@ -70,15 +70,19 @@ __device__ __forceinline__ uint32_t pack4(uint32_t b0, uint32_t b1, uint32_t b2,
 #define IAK_NT_STENCIL_ST 1
 #endif
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// 16 bytes from / to GLOBAL memory at any alignment: still one dwordx4 instruction (the device
+// handles unaligned vector memory accesses), so images at odd addresses and batches of images
+// with an odd number of pixels take the same 16-pixel paths as aligned ones.
+typedef u32x4 u32x4_any __attribute__((aligned(1)));
 template <bool NT = false>
 __device__ __forceinline__ u32x4 ld16(const uint8_t *p) {
-    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    return *reinterpret_cast<const u32x4 *>(p);
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4_any *>(p));
+    return *reinterpret_cast<const u32x4_any *>(p);
 }
 template <bool NT = false>
 __device__ __forceinline__ void st16(uint8_t *p, u32x4 v) {
-    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
-    else *reinterpret_cast<u32x4 *>(p) = v;
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_any *>(p));
+    else *reinterpret_cast<u32x4_any *>(p) = v;
 }
 template <bool NT = false>
 __device__ __forceinline__ void st8(uint8_t *p, uint32_t lo, uint32_t hi) {

@@ -884,9 +884,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
                 p->split[gi] = 1;
                 IAK_HIP(hipEventRecord(ev[2 * gi + 1], s));
             }
-            bool vec = aligned16(cur) && aligned16(dst) && N % 16 == 0;
-            for (int k = 0; k < g.chain.n; k++)
-                if (g.chain.st[k].plane && g.chain.st[k].type != C_KMEANS) vec = vec && aligned16(g.chain.st[k].plane);
+            const bool vec = true;  // 16-byte accesses work at any alignment; the last N % 16 pixels go one by one
             if (g.emit_hist) {
                 // few, large workgroups: each pays a 32 KiB table and a 256-atomic merge.  The table
                 // prologue above has consumed the old histogram (stream order), so hist2 can be reused.

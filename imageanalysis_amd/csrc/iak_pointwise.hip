@@ -13,7 +13,7 @@ namespace iak {
 //   void begin(int b)                       per-image set-up (may use LDS + __syncthreads)
 //   u32x4 apply16(u32x4 px, long long off)  16 pixels starting at byte offset off
 //   uint32_t apply1(uint32_t px, long long off)
-// VEC=false is the fallback for bases/strides that are not 16-byte aligned.
+// VEC=false: one pixel per lane throughout (kept for comparison; 16-byte accesses need no alignment).
 // ---------------------------------------------------------------------------------------
 template <bool VEC, class F>
 __global__ __launch_bounds__(256) void pointwise_kernel(const uint8_t *__restrict__ in,
@@ -41,7 +41,8 @@ template <class F>
 static int launch_pointwise(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride,
                             long long out_stride, F f, bool extra_aligned, void *stream) {
     if (!in || !out || N <= 0 || B <= 0) return IAK_E_ARG;
-    bool vec = aligned16(in) && aligned16(out) && (in_stride % 16 == 0) && (out_stride % 16 == 0) && extra_aligned;
+    (void)extra_aligned;
+    const bool vec = true;  // 16-byte accesses work at any alignment; the last N % 16 pixels go one by one
     long long items = vec ? ((N + 15) >> 4) : N;
     dim3 grid(blocks_x(items, 256, B), B);
     if (vec)
@@ -299,7 +300,7 @@ extern "C" {
 static int gray_launch(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B, long long rgb_stride,
                        long long gray_stride, int method, void *stream) {
     const long long N = (long long)W * H;
-    const bool vec = aligned16(rgb) && aligned16(gray) && rgb_stride % 16 == 0 && gray_stride % 16 == 0 && N % 16 == 0;
+    const bool vec = true;  // 16-byte accesses work at any alignment; the last N % 16 pixels go one by one
     hipStream_t s = as_stream(stream);
     dim3 block(GRAY_THREADS);
     if (hist) {
@@ -357,10 +358,7 @@ int iak_hist(const uint8_t *img, uint32_t *hist, long long N, int B, long long s
     hipStream_t s = as_stream(stream);
     IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
     dim3 grid(hist_blocks_x(N, B), B);
-    if (aligned16(img) && stride % 16 == 0)
-        hipLaunchKernelGGL((hist_kernel<true>), grid, dim3(256), 0, s, img, hist, N, stride);
-    else
-        hipLaunchKernelGGL((hist_kernel<false>), grid, dim3(256), 0, s, img, hist, N, stride);
+    hipLaunchKernelGGL((hist_kernel<true>), grid, dim3(256), 0, s, img, hist, N, stride);
     IAK_LAUNCH_CHECK();
     return 0;
 }
