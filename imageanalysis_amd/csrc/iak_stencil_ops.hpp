@@ -369,6 +369,65 @@ struct Compass8 {
     }
 };
 
+// Linear / average filter with integral weights whose sums fit 16 bits (255 * sum |w| <= 32767):
+// two pixels per instruction on 16-bit pairs, rows unpacked as for Sobel8.  Integer arithmetic
+// is exact, so the per-tap truncation of the reference changes nothing and the order of the
+// taps does not matter.
+struct PkRow {
+    s16x2 o[5], e[4];  // O_k = (p[2k-1], p[2k]), E_k = (p[2k], p[2k+1])
+};
+template <bool AVERAGE>
+struct Lin8Pk16 {
+    static const bool kBorderZero = true;
+    typedef PkRow Row;
+    s16x2 k[9];  // each weight in both halves
+    __device__ __forceinline__ static s16x2 pr(uint32_t hi_src, uint32_t lo_src, uint32_t sel) {
+        return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(hi_src, lo_src, sel));
+    }
+    __device__ __forceinline__ void prepare(const Raw16 &q, int, int, int, int, PkRow &r) const {
+        r.o[0] = pr(q.d[1], q.d[0], 0x0c040c03u);
+        r.o[1] = pr(q.d[1], q.d[1], 0x0c020c01u);
+        r.o[2] = pr(q.d[2], q.d[1], 0x0c040c03u);
+        r.o[3] = pr(q.d[2], q.d[2], 0x0c020c01u);
+        r.o[4] = pr(q.d[3], q.d[2], 0x0c040c03u);
+        r.e[0] = pr(q.d[1], q.d[1], 0x0c010c00u);
+        r.e[1] = pr(q.d[1], q.d[1], 0x0c030c02u);
+        r.e[2] = pr(q.d[2], q.d[2], 0x0c010c00u);
+        r.e[3] = pr(q.d[2], q.d[2], 0x0c030c02u);
+    }
+    __device__ __forceinline__ void compute(const PkRow &u, const PkRow &m, const PkRow &d, uint32_t o[2]) const {
+        s16x2 sum[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            s16x2 s = u.o[p] * k[0];
+            s += u.e[p] * k[1];
+            s += u.o[p + 1] * k[2];
+            s += m.o[p] * k[3];
+            s += m.e[p] * k[4];
+            s += m.o[p + 1] * k[5];
+            s += d.o[p] * k[6];
+            s += d.e[p] * k[7];
+            s += d.o[p + 1] * k[8];
+            sum[p] = s;
+        }
+        if (AVERAGE) {
+            int res[8];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                res[2 * p] = (int)sum[p].x / 9;  // imageAnalysis.cu:487: no clamp, the low byte is kept
+                res[2 * p + 1] = (int)sum[p].y / 9;
+            }
+            pack8(res, o);
+        } else {
+            const s16x2 zero = {0, 0}, top = {255, 255};
+#pragma unroll
+            for (int p = 0; p < 4; p++) sum[p] = __builtin_elementwise_min(__builtin_elementwise_max(sum[p], zero), top);
+            o[0] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, sum[1]), __builtin_bit_cast(uint32_t, sum[0]), 0x06040200u);
+            o[1] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, sum[3]), __builtin_bit_cast(uint32_t, sum[2]), 0x06040200u);
+        }
+    }
+};
+
 // 3x3 median, all weights 1: sort each of the 10 columns once (min3 / med3 / max3), then per
 // output the max of the three lows, the median of the three middles, the min of the three
 // highs, and the median of those.
@@ -504,7 +563,7 @@ struct Dilate8 {
 };
 
 // ---- host side: which exact-arithmetic path a 3x3 linear kernel admits ----------------------
-enum LinKind { LIN_INT, LIN_FIXED, LIN_FLOAT, LIN_SWAR };
+enum LinKind { LIN_INT, LIN_FIXED, LIN_FLOAT, LIN_SWAR, LIN_PK16 };
 
 struct LinPlan {
     LinKind kind;
@@ -543,7 +602,7 @@ inline LinPlan plan_linear3(const float *kernel) {
         mag += 255.0 * (kernel[i] < 0 ? -kernel[i] : kernel[i]);
     }
     if (integral && mag < 8388608.0) {  // every partial sum exact in float and within 24 bits
-        p.kind = LIN_INT;
+        p.kind = mag <= 32767.0 ? LIN_PK16 : LIN_INT;
         for (int i = 0; i < 9; i++) p.ik[i] = (int)kernel[i];
         return p;
     }
@@ -577,9 +636,14 @@ inline LinPlan plan_linear3(const float *kernel) {
 template <bool AVG, class L>
 inline int with_linear3_op(const float *kernel, L launch) {
     LinPlan p = plan_linear3(kernel);
-    if (!AVG && p.kind != LIN_INT && plan_swar(kernel, p)) {
+    if (!AVG && p.kind != LIN_INT && p.kind != LIN_PK16 && plan_swar(kernel, p)) {
         Lin8Swar op;
         op.sa = p.sa; op.sb = p.sb; op.sc = p.sc;
+        return launch(op);
+    }
+    if (p.kind == LIN_PK16) {
+        Lin8Pk16<AVG> op;
+        for (int i = 0; i < 9; i++) op.k[i] = s16x2{(short)p.ik[i], (short)p.ik[i]};
         return launch(op);
     }
     if (p.kind == LIN_INT) {
