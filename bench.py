@@ -42,10 +42,10 @@ P_A = [
 ]
 # launch group -> the HIP kernel that does its image pass (names as rocprofv3 prints them)
 KERNEL_OF_GROUP = {
-    "gray+hist": "iak::gray_kernel<0, true, true>",
+    "gray+hist": "iak::gray_kernel<0, true>",
     "equalize+gauss+salt_pepper+linear+median+sobel": "iak::strip_kernel",
     "equalize+gauss+salt_pepper+linear": "iak::chain_stencil8_kernel<iak::Lin8Swar>",
-    "equalize+gauss+salt_pepper": "iak::chain_apply_kernel<true>",
+    "equalize+gauss+salt_pepper": "iak::chain_apply_kernel<false>",
     "linear": "iak::stencil8_kernel<iak::Lin8Swar, 8, false, false>",
     "median": "iak::stencil8_kernel<iak::Median8, 8, false, false>",
     "sobel": "iak::stencil8_kernel<iak::Sobel8, 8, false, false>",
@@ -53,7 +53,7 @@ KERNEL_OF_GROUP = {
 # kernels behind the group names of the other two workloads, where they differ from P-A's
 KERNEL_OF_GROUP_BY_WORKLOAD = {
     "P-B": {"linear": "iak::tiled_linear_kernel<11, false, true>", "median": "iak::huang_median_kernel<7>"},
-    "P-C": {"otsu": "iak::chain_apply_kernel<true>", "otsu+sobel": "iak::binary_table_stencil_kernel",
+    "P-C": {"otsu": "iak::chain_apply_kernel<false>", "otsu+sobel": "iak::binary_table_stencil_kernel",
             "dilate+erode+hist": "iak::morph_chain_kernel<2, 2, false>", "features": "iak::perimeter_bits_kernel"},
 }
 # The histogram rides on the grayscale pass (the pixel is still in a register), so that kernel's

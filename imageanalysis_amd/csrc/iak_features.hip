@@ -26,10 +26,9 @@ namespace iak {
 
 // One workgroup of 256 lanes per image, lane v = grey value v.
 // features[b] = {mean, std, area, (perimeter: later), mode, rangeMin, rangeMax};
-// tables[b][0][v] = Otsu mask value of v; counts[b] = 0; thr_out[b] = the threshold.
+// counts[b] = 0; thr_out[b] = the Otsu threshold (the mask is pixel > threshold, imageAnalysis.cu:207-216).
 __global__ __launch_bounds__(256) void features_stats_kernel(const uint32_t *__restrict__ hist, int numPixels, int B,
-                                                             float *__restrict__ features,
-                                                             uint16_t *__restrict__ tables, uint32_t *__restrict__ counts,
+                                                             float *__restrict__ features, uint32_t *__restrict__ counts,
                                                              int32_t *__restrict__ thr_out) {
     __shared__ BlockScratch bs;
     const int b = blockIdx.x, v = threadIdx.x;
@@ -48,7 +47,6 @@ __global__ __launch_bounds__(256) void features_stats_kernel(const uint32_t *__r
     // range (:379-390): first and last non-empty bin, -1 when there is none
     const long long lo_key = block_max_ll(hv ? (long long)(255 - v) : -1, bs.red);
     const long long hi_key = block_max_ll(hv ? (long long)v : -1, bs.red);
-    tables[(long long)b * CHAIN_MAX * 256 + v] = v > thr ? 255 : 0;  // thresholdImage (imageAnalysis.cu:207-216)
     if (v == 0) {
         float *f = features + (long long)b * FEAT_N;
         f[0] = mean;
@@ -324,7 +322,7 @@ long long iak_features_workspace_bytes(int W, int H, int B) {
     const long long N = (long long)W * H;
     long long bytes = 0;
     bytes += (long long)B * 256 * 4;              // histogram of the image
-    bytes += (long long)B * CHAIN_MAX * 256 * 2;  // mask table
+    bytes += (long long)B * CHAIN_MAX * 256 * 2;  // (reserved)
     bytes += (long long)B * 4 * 2;                // edge counts, thresholds
     bytes = (bytes + 255) & ~255LL;
     if (W % 16 != 0 || N >= (1LL << 30)) bytes += 2 * (((long long)B * N + 255) & ~255LL) + (long long)B * 256 * 4;  // mask, edges, their histogram
@@ -340,7 +338,6 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
     hipStream_t s = as_stream(stream);
     uint8_t *ws = static_cast<uint8_t *>(workspace);
     uint32_t *own_hist = reinterpret_cast<uint32_t *>(ws);
-    uint16_t *tables = reinterpret_cast<uint16_t *>(ws + (size_t)B * 256 * 4);
     uint32_t *counts = reinterpret_cast<uint32_t *>(ws + (size_t)B * 256 * 4 + (size_t)B * CHAIN_MAX * 256 * 2);
     int32_t *thr = reinterpret_cast<int32_t *>(counts + B);
     size_t head = (size_t)B * 256 * 4 + (size_t)B * CHAIN_MAX * 256 * 2 + (size_t)B * 8;
@@ -350,8 +347,7 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
         if ((rc = iak_hist(img, own_hist, N, B, stride, stream))) return rc;
         hist = own_hist;
     }
-    hipLaunchKernelGGL(features_stats_kernel, dim3(B), dim3(256), 0, s, hist, (int)N, B, features, tables, counts,
-                       thr);
+    hipLaunchKernelGGL(features_stats_kernel, dim3(B), dim3(256), 0, s, hist, (int)N, B, features, counts, thr);
     IAK_LAUNCH_CHECK();
     if (W % 16 == 0 && N < (1LL << 30)) {
         // the workspace for this shape holds no image buffers: the one-pass form is the only one

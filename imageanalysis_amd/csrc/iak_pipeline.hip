@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *__restr
 
 // HIST: also accumulates the histogram of the output (hist[b][256], zeroed by the launcher, bin 0
 // left empty), for the consumer behind this run.
-template <bool VEC, bool HIST = false>
+template <bool HIST = false>
 __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                           long long N, long long in_stride, long long out_stride,
                                                           ChainDesc d, const uint16_t *__restrict__ tables,
@@ -143,8 +143,7 @@ __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restr
     uint8_t *dst = out + (long long)b * out_stride;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
-    long long scalar_from = 0;
-    if (VEC) {
+    {
         // two chunks per iteration: their loads are issued together, so a wave always has two
         // independent request / look-up chains in flight
         const long long nchunks = N >> 4;
@@ -167,8 +166,8 @@ __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restr
                 }
             }
         }
-        scalar_from = nchunks << 4;
     }
+    const long long scalar_from = (N >> 4) << 4;
     for (long long x = scalar_from + tid; x < N; x += nthreads) {
         const uint32_t y = chain_apply1(src[x], x, d, t) & 0xffu;
         dst[x] = (uint8_t)y;
@@ -884,27 +883,18 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
                 p->split[gi] = 1;
                 IAK_HIP(hipEventRecord(ev[2 * gi + 1], s));
             }
-            const bool vec = true;  // 16-byte accesses work at any alignment; the last N % 16 pixels go one by one
             if (g.emit_hist) {
                 // few, large workgroups: each pays a 32 KiB table and a 256-atomic merge.  The table
                 // prologue above has consumed the old histogram (stream order), so hist2 can be reused.
                 IAK_HIP(hipMemsetAsync(sl.hist2, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
-                dim3 grid(blocks_x(vec ? N / 32 : N, 256, B, 4096), B);
-                if (vec)
-                    hipLaunchKernelGGL((chain_apply_kernel<true, true>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd, sl.tables,
-                                       sl.hist2);
-                else
-                    hipLaunchKernelGGL((chain_apply_kernel<false, true>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd,
-                                       sl.tables, sl.hist2);
+                dim3 grid(blocks_x((N + 31) / 32, 256, B, 4096), B);
+                hipLaunchKernelGGL((chain_apply_kernel<true>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd, sl.tables, sl.hist2);
                 IAK_LAUNCH_CHECK();
                 cur_hist = sl.hist2;
                 break;
             }
-            dim3 grid(blocks_x(vec ? N / 32 : N, 256, B, 32768), B);
-            if (vec)
-                hipLaunchKernelGGL((chain_apply_kernel<true>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd, sl.tables);
-            else
-                hipLaunchKernelGGL((chain_apply_kernel<false>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd, sl.tables);
+            dim3 grid(blocks_x((N + 31) / 32, 256, B, 32768), B);
+            hipLaunchKernelGGL((chain_apply_kernel<false>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd, sl.tables);
             IAK_LAUNCH_CHECK();
             cur_hist = nullptr;
             break;

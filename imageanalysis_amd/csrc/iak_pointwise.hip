@@ -13,9 +13,9 @@ namespace iak {
 //   void begin(int b)                       per-image set-up (may use LDS + __syncthreads)
 //   u32x4 apply16(u32x4 px, long long off)  16 pixels starting at byte offset off
 //   uint32_t apply1(uint32_t px, long long off)
-// VEC=false: one pixel per lane throughout (kept for comparison; 16-byte accesses need no alignment).
+// 16-byte accesses need no alignment; the last N % 16 pixels of an image go one by one.
 // ---------------------------------------------------------------------------------------
-template <bool VEC, class F>
+template <class F>
 __global__ __launch_bounds__(256) void pointwise_kernel(const uint8_t *__restrict__ in,
                                                         uint8_t *__restrict__ out, long long N,
                                                         long long in_stride, long long out_stride, F f) {
@@ -25,32 +25,20 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const uint8_t *__restric
     f.begin(b);
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
-    if (VEC) {
-        const long long nchunks = N >> 4;
-        for (long long c = tid; c < nchunks; c += nthreads) {
-            u32x4 v = ld16<IAK_NT_CHAIN_LD>(src + (c << 4));
-            st16<IAK_NT_CHAIN_ST>(dst + (c << 4), f.apply16(v, c << 4));
-        }
-        for (long long t = (nchunks << 4) + tid; t < N; t += nthreads) dst[t] = (uint8_t)f.apply1(src[t], t);
-    } else {
-        for (long long t = tid; t < N; t += nthreads) dst[t] = (uint8_t)f.apply1(src[t], t);
+    const long long nchunks = N >> 4;
+    for (long long c = tid; c < nchunks; c += nthreads) {
+        u32x4 v = ld16<IAK_NT_CHAIN_LD>(src + (c << 4));
+        st16<IAK_NT_CHAIN_ST>(dst + (c << 4), f.apply16(v, c << 4));
     }
+    for (long long t = (nchunks << 4) + tid; t < N; t += nthreads) dst[t] = (uint8_t)f.apply1(src[t], t);
 }
 
 template <class F>
 static int launch_pointwise(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride,
-                            long long out_stride, F f, bool extra_aligned, void *stream) {
+                            long long out_stride, F f, void *stream) {
     if (!in || !out || N <= 0 || B <= 0) return IAK_E_ARG;
-    (void)extra_aligned;
-    const bool vec = true;  // 16-byte accesses work at any alignment; the last N % 16 pixels go one by one
-    long long items = vec ? ((N + 15) >> 4) : N;
-    dim3 grid(blocks_x(items, 256, B), B);
-    if (vec)
-        hipLaunchKernelGGL((pointwise_kernel<true, F>), grid, dim3(256), 0, as_stream(stream), in, out, N, in_stride,
-                           out_stride, f);
-    else
-        hipLaunchKernelGGL((pointwise_kernel<false, F>), grid, dim3(256), 0, as_stream(stream), in, out, N, in_stride,
-                           out_stride, f);
+    dim3 grid(blocks_x((N + 15) >> 4, 256, B), B);
+    hipLaunchKernelGGL((pointwise_kernel<F>), grid, dim3(256), 0, as_stream(stream), in, out, N, in_stride, out_stride, f);
     IAK_LAUNCH_CHECK();
     return 0;
 }
@@ -187,7 +175,7 @@ __device__ __forceinline__ uint32_t gray4(uint32_t r, uint32_t g, uint32_t b) {
 
 // 1024 lanes share one 32 KiB histogram table, so two workgroups (32 waves) fit a CU.
 #define GRAY_THREADS 1024
-template <int METHOD, bool HIST, bool VEC>
+template <int METHOD, bool HIST>
 __global__ __launch_bounds__(GRAY_THREADS) void gray_kernel(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ gray,
                                                             uint32_t *__restrict__ hist, long long N,
                                                             long long rgb_stride, long long gray_stride) {
@@ -201,8 +189,7 @@ __global__ __launch_bounds__(GRAY_THREADS) void gray_kernel(const uint8_t *__res
     if (HIST) hist_zero(sh);
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
-    long long scalar_from = 0;
-    if (VEC) {
+    {
         // two chunks per iteration so that six loads are in flight per lane
         const long long nchunks = N >> 4;
         for (long long c = tid; c < nchunks; c += 2 * nthreads) {
@@ -232,8 +219,8 @@ __global__ __launch_bounds__(GRAY_THREADS) void gray_kernel(const uint8_t *__res
                 }
             }
         }
-        scalar_from = nchunks << 4;
     }
+    const long long scalar_from = (N >> 4) << 4;
     for (long long t = scalar_from + tid; t < N; t += nthreads) {
         uint32_t y = METHOD == 2 ? R[t] : (METHOD == 0 ? lum1(R[t], G[t], Bp[t]) : avg1(R[t], G[t], Bp[t]));
         dst[t] = (uint8_t)y;
@@ -242,7 +229,6 @@ __global__ __launch_bounds__(GRAY_THREADS) void gray_kernel(const uint8_t *__res
     if (HIST) hist_flush(sh, hist + (long long)b * 256);
 }
 
-template <bool VEC>
 __global__ __launch_bounds__(256) void hist_kernel(const uint8_t *__restrict__ img, uint32_t *__restrict__ hist,
                                                    long long N, long long stride) {
     __shared__ uint32_t sh[256 * HIST_COLS];
@@ -252,16 +238,13 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t *__restrict__ i
     hist_zero(sh);
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
-    long long scalar_from = 0;
-    if (VEC) {
-        const long long nchunks = N >> 4;
-        for (long long c = tid; c < nchunks; c += nthreads) {
-            u32x4 v = ld16(src + (c << 4));
+    const long long nchunks = N >> 4;
+    for (long long c = tid; c < nchunks; c += nthreads) {
+        u32x4 v = ld16(src + (c << 4));
 #pragma unroll
-            for (int w = 0; w < 4; w++) hist_add4(sh, v[w], col);
-        }
-        scalar_from = nchunks << 4;
+        for (int w = 0; w < 4; w++) hist_add4(sh, v[w], col);
     }
+    const long long scalar_from = nchunks << 4;
     for (long long t = scalar_from + tid; t < N; t += nthreads) atomicAdd(&sh[src[t] * HIST_COLS + col], 1u);
     hist_flush(sh, hist + (long long)b * 256);
 }
@@ -300,7 +283,6 @@ extern "C" {
 static int gray_launch(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B, long long rgb_stride,
                        long long gray_stride, int method, void *stream) {
     const long long N = (long long)W * H;
-    const bool vec = true;  // 16-byte accesses work at any alignment; the last N % 16 pixels go one by one
     hipStream_t s = as_stream(stream);
     dim3 block(GRAY_THREADS);
     if (hist) {
@@ -313,17 +295,17 @@ static int gray_launch(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W,
         if (bx > by_work) bx = by_work;
         if (bx < 1) bx = 1;
         dim3 grid((unsigned)bx, B);
-#define GH(M, V) hipLaunchKernelGGL((gray_kernel<M, true, V>), grid, block, 0, s, rgb, gray, hist, N, rgb_stride, gray_stride)
-        if (method == 0) { if (vec) GH(0, true); else GH(0, false); }
-        else if (method == 1) { if (vec) GH(1, true); else GH(1, false); }
-        else { if (vec) GH(2, true); else GH(2, false); }
+#define GH(M) hipLaunchKernelGGL((gray_kernel<M, true>), grid, block, 0, s, rgb, gray, hist, N, rgb_stride, gray_stride)
+        if (method == 0) GH(0);
+        else if (method == 1) GH(1);
+        else GH(2);
 #undef GH
     } else {
-        dim3 grid(blocks_x(vec ? N / 32 : N, GRAY_THREADS, B, 2048), B);
-#define GN(M, V) hipLaunchKernelGGL((gray_kernel<M, false, V>), grid, block, 0, s, rgb, gray, (uint32_t *)nullptr, N, rgb_stride, gray_stride)
-        if (method == 0) { if (vec) GN(0, true); else GN(0, false); }
-        else if (method == 1) { if (vec) GN(1, true); else GN(1, false); }
-        else { if (vec) GN(2, true); else GN(2, false); }
+        dim3 grid(blocks_x((N + 31) / 32, GRAY_THREADS, B, 2048), B);
+#define GN(M) hipLaunchKernelGGL((gray_kernel<M, false>), grid, block, 0, s, rgb, gray, (uint32_t *)nullptr, N, rgb_stride, gray_stride)
+        if (method == 0) GN(0);
+        else if (method == 1) GN(1);
+        else GN(2);
 #undef GN
     }
     IAK_LAUNCH_CHECK();
@@ -358,7 +340,7 @@ int iak_hist(const uint8_t *img, uint32_t *hist, long long N, int B, long long s
     hipStream_t s = as_stream(stream);
     IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
     dim3 grid(hist_blocks_x(N, B), B);
-    hipLaunchKernelGGL((hist_kernel<true>), grid, dim3(256), 0, s, img, hist, N, stride);
+    hipLaunchKernelGGL(hist_kernel, grid, dim3(256), 0, s, img, hist, N, stride);
     IAK_LAUNCH_CHECK();
     return 0;
 }
@@ -378,7 +360,7 @@ int iak_apply_map(const uint8_t *in, uint8_t *out, long long N, int B, long long
                   const int32_t *map, long long map_stride, void *stream) {
     if (!map || (map_stride != 0 && map_stride < 256)) return IAK_E_ARG;
     MapFn f{map, map_stride, nullptr};
-    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, true, stream);
+    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, stream);
 }
 
 int iak_quantize(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride, long long out_stride,
@@ -397,34 +379,34 @@ int iak_quantize(const uint8_t *in, uint8_t *out, long long N, int B, long long 
         f.t.v[v] = o;
     }
     f.lut_ = nullptr;
-    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, true, stream);
+    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, stream);
 }
 
 int iak_threshold(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride, long long out_stride,
                   int threshold, void *stream) {
     ThresholdFn f{threshold, nullptr};
-    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, true, stream);
+    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, stream);
 }
 
 int iak_threshold_per_image(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride,
                             long long out_stride, const int32_t *thr, void *stream) {
     if (!thr) return IAK_E_ARG;
     ThresholdFn f{0, thr};
-    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, true, stream);
+    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, stream);
 }
 
 int iak_salt_pepper(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride, long long out_stride,
                     const uint8_t *sp, void *stream) {
     if (!sp) return IAK_E_ARG;
     SaltPepperFn f{sp};
-    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, aligned16(sp), stream);
+    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, stream);
 }
 
 int iak_gauss_noise(const uint8_t *in, uint8_t *out, long long N, int B, long long in_stride, long long out_stride,
                     const uint8_t *rv, const uint16_t *table, long long table_stride, void *stream) {
     if (!rv || !table || (table_stride != 0 && table_stride < 256)) return IAK_E_ARG;
     GaussFn f{rv, table, table_stride, nullptr};
-    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, aligned16(rv), stream);
+    return launch_pointwise(in, out, N, B, in_stride, out_stride, f, stream);
 }
 
 }  // extern "C"

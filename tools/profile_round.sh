@@ -33,7 +33,7 @@ for kind in C K U; do
         --only gray_hist,hist --reps 5 --kind $kind > /tmp/pmc_hist_$kind.log 2>&1
     {
         echo "# kind $kind: $(grep -E '^(gray_hist|hist) ' /tmp/pmc_hist_$kind.log | tr -s ' ' | tr '\n' ';')"
-        python3 tools/pmc_summary.py /tmp/pmc_hist_$kind | grep -A8 -E "gray_kernel<0, true, true>|hist_kernel"
+        python3 tools/pmc_summary.py /tmp/pmc_hist_$kind | grep -A8 -E "gray_kernel<0, true>|hist_kernel"
     } >> "$out/pmc_sq_histogram.txt"
 done
 python3 tools/make_traffic.py /tmp/pmc_fetch /tmp/pmc_write 500 "$out/traffic.json" > /dev/null
