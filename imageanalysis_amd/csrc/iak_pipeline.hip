@@ -31,8 +31,11 @@ namespace iak {
 // use the low byte).  Everything that is order-free is done across lanes; the two float
 // accumulations whose order the reference fixes (the cdf, the variance sum) are added up by
 // one lane in bin order from per-lane terms.
-__global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *__restrict__ hist_in, int numPixels,
-                                                         ChainDesc d, uint16_t *__restrict__ tables) {
+// hist_out (may be null, may be hist_in): the histogram of the run's OUTPUT, for runs made of
+// look-up stages only -- it is the input's histogram pushed through the tables, so the consumer
+// behind the run needs no counting pass.
+__global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *hist_in, int numPixels, ChainDesc d,
+                                                         uint16_t *__restrict__ tables, uint32_t *hist_out = nullptr) {
     __shared__ uint32_t h[256];  // current histogram, bin 0 empty
     __shared__ uint32_t h2[256];
     __shared__ BlockScratch bs;
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *__restr
         h[v] = (v == 0) ? 0u : h2[v];
         __syncthreads();
     }
+    if (hist_out) hist_out[(long long)b * 256 + v] = h[v];
 }
 
 // HIST: also accumulates the histogram of the output (hist[b][256], zeroed by the launcher, bin 0
@@ -222,6 +226,8 @@ struct Group {
     bool chain_needs_hist = false;
     StripDesc strip;      // G_STRIP
     bool emit_hist = false;  // G_CHAIN, G_OP: the pass also leaves the histogram of its output
+    bool hist_from_tables = false;  // G_CHAIN of look-up stages only: that histogram comes from the table prologue
+    bool hist_tracked = false;      // G_CHAIN: the prologue has the input's histogram and every stage carries it on
     bool binary = false;     // G_CHAIN_OP: the run is one threshold, the stencil is done by table (bt)
     BinTable bt;
 };
@@ -460,6 +466,7 @@ static int plan(iak_pipeline *p) {
                 first = false;
                 i++;
             }
+            g.hist_tracked = chain_hist;
             if (g.chain_needs_hist) {
                 Group gh;
                 gh.kind = G_HIST;
@@ -580,8 +587,15 @@ static int plan(iak_pipeline *p) {
             const bool stencil_ok = prev.kind == G_OP && is_fusable_stencil(p->ops[prev.op_index].op) && p->W >= 8 &&
                                     (long long)p->W * p->H < (1LL << 30);
             if (prev.kind != G_CHAIN && prev.kind != G_MORPH && !stencil_ok) continue;
-            prev.emit_hist = true;
-            prev.alg_bytes += 1;
+            bool luts_only = prev.kind == G_CHAIN && prev.hist_tracked;
+            for (int q = 0; luts_only && q < prev.chain.n; q++)
+                luts_only = prev.chain.st[q].type != C_GAUSS && prev.chain.st[q].type != C_SP;
+            if (luts_only) {
+                prev.hist_from_tables = true;  // no counting at all
+            } else {
+                prev.emit_hist = true;
+                prev.alg_bytes += 1;
+            }
             prev.name += "+hist";
             p->groups.erase(p->groups.begin() + (long)k);
             k--;
@@ -877,7 +891,10 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
                 wants = wants || g.chain.st[k].type == C_EQUALIZE || g.chain.st[k].type == C_OTSU || g.chain.st[k].type == C_KMEANS ||
                         (g.chain.st[k].type == C_GAUSS && (g.chain.st[k].mean == -1 || g.chain.st[k].stddev == -1));
             if (wants && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
-            hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables);
+            // hist_from_tables: a workgroup reads its image's old histogram before it writes the new one,
+            // so hist2 can be both
+            hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables,
+                               g.hist_from_tables ? sl.hist2 : (uint32_t *)nullptr);
             IAK_LAUNCH_CHECK();
             if (ev) {
                 p->split[gi] = 1;
@@ -896,7 +913,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             dim3 grid(blocks_x((N + 31) / 32, 256, B, 32768), B);
             hipLaunchKernelGGL((chain_apply_kernel<false>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd, sl.tables);
             IAK_LAUNCH_CHECK();
-            cur_hist = nullptr;
+            cur_hist = g.hist_from_tables ? sl.hist2 : nullptr;
             break;
         }
         case G_CHAIN_OP: {

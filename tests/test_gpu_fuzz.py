@@ -91,7 +91,7 @@ def test_fuzz_pipeline(case):
                                  f"first {bad[0]}, ops {ops}")
         assert np.array_equal(hs.cpu().numpy(), want_hist), (case, mode)
         if has_features:
-            assert np.array_equal(feats.cpu().numpy(), want_feats), (case, mode, names)
+            assert np.array_equal(feats.cpu().numpy(), want_feats, equal_nan=True), (case, mode, names)  # 1x1 images: std is NaN
         p.close()
 
 
