@@ -127,9 +127,15 @@ def cpu_baseline(rgb_dev, n_threads, ops):
     t0 = time.perf_counter()
     out, _ = O.pipeline(sample, ops, x0, x1, threads=n_threads)
     dt = time.perf_counter() - t0
+    # the same on one core, on about 2 s worth of images, for the per-core rate
+    n1 = int(max(1, min(n, 2.0 / max(per_image_cpu_s, 1e-6))))
+    t1 = time.perf_counter()
+    O.pipeline(sample[:n1], ops, x0, x1, threads=1)
+    dt1 = time.perf_counter() - t1
     return {
         "value": round(n * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "cores": n_threads, "kind": "port",
         "sample": f"{n} of the batch's {W}x{H} images, same pipeline, OpenMP over images, {dt:.2f} s wall",
+        "value_1_core": round(n1 * W * H / dt1 / 1e6, 2), "host_cpus": os.cpu_count(),
     }, out, n
 
 
