@@ -204,18 +204,54 @@ __global__ __launch_bounds__(256) void tiled_morph_kernel(const uint8_t *__restr
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int x0 = tx * TL_TW, y0 = ty * TL_TH;
     const int rows = TL_TH + kH - 1, cols = TL_TW + kW - 1;
-    for (int e = threadIdx.x; e < rows * pitch; e += 256) {
-        const int r = e / pitch, c = e - r * pitch;
-        uint32_t v = 0;
-        if (c < cols) {
-            const long long idx = (long long)(y0 - a + r) * W + (x0 - s + c);
-            v = tap_at(src, N, idx);
-            if (!ERODE) {
-                const int urow = (int)(idx / W), ucol = (int)(idx - (long long)urow * W);  // idx < 0 gives v == 0 already
-                v = (v > 0 && !is_border(urow, ucol, W, H, a, s)) ? 1u : 0u;
+    // Staging: a wave per tile row, lanes along it (two passes cover the row and its padding);
+    // all of a wave's loads (up to 14 rows: the tile has at most 56) are issued before the first is
+    // used, so their latencies overlap.
+    // Taps come through a buffer descriptor over exactly the image (offsets outside [0, N),
+    // negative ones included as unsigned, read 0; clamped in a register so that the compiler
+    // cannot split them into a negative register part and a positive immediate).
+    const int Ni = (int)N;  // the launcher keeps W * (H + 32) below 2^31
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, Ni, 0x00020000);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const int rb = wave;
+        uint32_t v[14][2];
+#pragma unroll
+        for (int u = 0; u < 14; u++) {
+            const int r = rb + 4 * u;
+            const int base = (y0 - a + r) * W + (x0 - s);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int c = lane + 64 * k;
+                const uint32_t o = (r < rows && c < cols) ? min((uint32_t)(base + c), (uint32_t)Ni) : (uint32_t)Ni;
+                v[u][k] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)o, 0, 0);
             }
         }
-        tile[e] = (uint8_t)v;
+#pragma unroll
+        for (int u = 0; u < 14; u++) {
+            const int r = rb + 4 * u;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int c = lane + 64 * k;
+                if (r < rows && c < pitch) {
+                    uint32_t val = c < cols ? v[u][k] : 0u;
+                    if (!ERODE && val) {
+                        // a source is foreground and not on ITS border: its true row and column on the flat view
+                        int urow = y0 - a + r, ucol = x0 - s + c;
+                        if (W >= 128) {  // at most one wrap either way (|column overhang| < 128)
+                            if (ucol < 0) { ucol += W; urow--; }
+                            else if (ucol >= W) { ucol -= W; urow++; }
+                        } else {
+                            const int g = urow * W + ucol;  // >= 0: the pixel exists
+                            urow = g / W;
+                            ucol = g - urow * W;
+                        }
+                        val = is_border(urow, ucol, W, H, a, s) ? 0u : 1u;
+                    }
+                    tile[r * pitch + c] = (uint8_t)val;
+                }
+            }
+        }
     }
     __syncthreads();
     const int lx = threadIdx.x & 7, ly = threadIdx.x >> 3;
@@ -264,7 +300,7 @@ __global__ __launch_bounds__(256) void tiled_morph_kernel(const uint8_t *__restr
 // path does not apply.
 static int launch_tiled_morph(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
                               long long out_stride, const int *se, int kWe, int kHe, bool erode, hipStream_t s) {
-    if (kWe > 25 || kHe > 25 || (long long)W * H >= (1LL << 31)) return IAK_E_UNSUPPORTED;
+    if (kWe > 25 || kHe > 25 || (long long)W * ((long long)H + 32) >= (1LL << 31)) return IAK_E_UNSUPPORTED;
     SeRows rows;
     for (int r = 0; r < 25; r++) rows.m[r] = 0;
     for (int r = 0; r < kHe; r++)
