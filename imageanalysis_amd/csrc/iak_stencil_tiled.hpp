@@ -174,18 +174,22 @@ static int launch_tiled_linear(const uint8_t *in, uint8_t *out, int W, int H, in
 }
 
 // ---------------------------------------------------------------------------------------
-// Erosion / dilation with structuring elements above 3x3 (odd window up to 25x25): the same
-// 64 x 32 output tile as the linear filter, on bit masks.  A lane owns 8 adjacent outputs of a
-// row; for each row of the structuring element it turns the 8+kW-1 staged bytes into a mask of
-// non-zero pixels and shifts it once per non-zero element: one AND (erosion) or OR (dilation)
-// covers all 8 outputs.
+// Erosion / dilation with structuring elements above 3x3 (odd window up to 25x25) on bit masks.
+// A workgroup of 256 lanes makes a 64 x 32 tile of outputs.  Staging turns the
+// (32+kH-1) x (64+kW-1) input tile straight into one bit per pixel: a wave takes a tile row,
+// its lanes the columns, and a ballot of "this pixel counts" is the row's mask (128 bits per row
+// in LDS).  A lane then owns 8 adjacent outputs of a row: per row of the structuring element it
+// cuts its 8+kW-1 bits out of the row mask and shifts them once per set element -- one AND
+// (erosion) or OR (dilation) covers all 8 outputs.
 //   erosion (imageAnalysis.cu:421-451): out = pixel if every element's tap is non-zero, else 0;
-//     border pixels 0.  The tile holds the pixels themselves.
+//     border pixels 0.  A pixel counts if it is non-zero.
 //   dilation (imageAnalysis.cu:381-404, a scatter from every non-border foreground pixel, the
 //     write race resolved as "255 wins"): out = 255 iff some element reaches the pixel from such
-//     a source, i.e. a gather through the mirrored element.  The tile holds 1 where the pixel is
-//     a source (foreground and not on ITS border, judged at its true row / column on the flat
-//     view), else 0.
+//     a source, i.e. a gather through the mirrored element.  A pixel counts if it is a source:
+//     foreground and not on ITS border, judged at its true row / column on the flat view.
+// Taps come through a buffer descriptor over exactly the image: offsets outside [0, N),
+// negative ones included as unsigned, read 0 (clamped in a register so that the compiler cannot
+// split them into a negative register part and a positive immediate).
 // ---------------------------------------------------------------------------------------
 struct SeRows {
     uint32_t m[25];  // bit j of m[r]: element (r, j) is set (dilation: already mirrored)
@@ -195,30 +199,37 @@ template <bool ERODE>
 __global__ __launch_bounds__(256) void tiled_morph_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
                                                           int H, long long in_stride, long long out_stride, int kW, int kH,
                                                           int tiles_x, SeRows se) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
-    const int pitch = ((TL_TW + kW - 1 + 3) / 4) * 4 + 4;
-    const long long N = (long long)W * H;
+    __shared__ uint32_t brow[(TL_TH + 24) * 4];  // [tile row][4 words]: bit c = tile column c counts
+    const int Ni = W * H;  // the launcher keeps W * (H + 32) below 2^31
     const uint8_t *src = in + (long long)blockIdx.y * in_stride;
     uint8_t *dst = out + (long long)blockIdx.y * out_stride;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, Ni, 0x00020000);
     const int a = (kH - 1) / 2, s = (kW - 1) / 2;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int x0 = tx * TL_TW, y0 = ty * TL_TH;
     const int rows = TL_TH + kH - 1, cols = TL_TW + kW - 1;
-    // Staging: a wave per tile row, lanes along it (two passes cover the row and its padding);
-    // all of a wave's loads (up to 14 rows: the tile has at most 56) are issued before the first is
-    // used, so their latencies overlap.
-    // Taps come through a buffer descriptor over exactly the image (offsets outside [0, N),
-    // negative ones included as unsigned, read 0; clamped in a register so that the compiler
-    // cannot split them into a negative register part and a positive immediate).
-    const int Ni = (int)N;  // the launcher keeps W * (H + 32) below 2^31
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, Ni, 0x00020000);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // dilation: where tile column c lies on the flat view -- how many rows further down (negative:
+    // up) and whether that column is off the border; the same for every tile row
+    int wraps[2] = {0, 0};
+    bool col_ok[2] = {true, true};
+    if (!ERODE) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int xc = x0 - s + lane + 64 * k;
+            int q = xc / W, ucol = xc - q * W;
+            if (ucol < 0) { ucol += W; q--; }
+            wraps[k] = q;
+            col_ok[k] = ucol >= s && ucol <= W - s;
+        }
+    }
     {
-        const int rb = wave;
+        // all of a wave's loads (up to 14 rows: the tile has at most 56) are issued before the first
+        // is used, so their latencies overlap
         uint32_t v[14][2];
 #pragma unroll
         for (int u = 0; u < 14; u++) {
-            const int r = rb + 4 * u;
+            const int r = wave + 4 * u;
             const int base = (y0 - a + r) * W + (x0 - s);
 #pragma unroll
             for (int k = 0; k < 2; k++) {
@@ -229,26 +240,20 @@ __global__ __launch_bounds__(256) void tiled_morph_kernel(const uint8_t *__restr
         }
 #pragma unroll
         for (int u = 0; u < 14; u++) {
-            const int r = rb + 4 * u;
+            const int r = wave + 4 * u;
+            if (r < rows) {  // uniform over the wave
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int c = lane + 64 * k;
-                if (r < rows && c < pitch) {
-                    uint32_t val = c < cols ? v[u][k] : 0u;
-                    if (!ERODE && val) {
-                        // a source is foreground and not on ITS border: its true row and column on the flat view
-                        int urow = y0 - a + r, ucol = x0 - s + c;
-                        if (W >= 128) {  // at most one wrap either way (|column overhang| < 128)
-                            if (ucol < 0) { ucol += W; urow--; }
-                            else if (ucol >= W) { ucol -= W; urow++; }
-                        } else {
-                            const int g = urow * W + ucol;  // >= 0: the pixel exists
-                            urow = g / W;
-                            ucol = g - urow * W;
-                        }
-                        val = is_border(urow, ucol, W, H, a, s) ? 0u : 1u;
+                for (int k = 0; k < 2; k++) {
+                    bool counts = v[u][k] != 0;  // columns past the tile were loaded as 0
+                    if (!ERODE) {  // a source is not on ITS border: its true row is the tile row's plus the wraps
+                        const int urow = y0 - a + r + wraps[k];
+                        counts = counts && col_ok[k] && urow >= a && urow <= H - a;
                     }
-                    tile[r * pitch + c] = (uint8_t)val;
+                    const unsigned long long m = __ballot(counts);
+                    if (lane == 0) {
+                        brow[r * 4 + 2 * k] = (uint32_t)m;
+                        brow[r * 4 + 2 * k + 1] = (uint32_t)(m >> 32);
+                    }
                 }
             }
         }
@@ -257,12 +262,11 @@ __global__ __launch_bounds__(256) void tiled_morph_kernel(const uint8_t *__restr
     const int lx = threadIdx.x & 7, ly = threadIdx.x >> 3;
     const int row = y0 + ly, col0 = x0 + lx * 8;
     if (row >= H || col0 >= W) return;
-    const int nw = (8 + kW - 1 + 3) >> 2;  // dwords that cover the lane's 8+kW-1 pixels
+    const int wi = (lx * 8) >> 5, sh = (lx * 8) & 31;
     uint32_t acc = ERODE ? 0xffu : 0u;
     for (int r = 0; r < kH; r++) {
-        const uint32_t *rp = reinterpret_cast<const uint32_t *>(tile + (ly + r) * pitch + lx * 8);
-        uint32_t bits = 0;
-        for (int w = 0; w < nw; w++) bits |= nonzero4(rp[w]) << (4 * w);
+        // the 32 row bits from tile column 8 * lx on: the lane's 8 + kW - 1 columns and more
+        const uint32_t bits = __builtin_amdgcn_alignbit(brow[(ly + r) * 4 + wi + 1], brow[(ly + r) * 4 + wi], (uint32_t)sh);
         uint32_t m = se.m[r];
         for (int j = 0; m != 0; j++, m >>= 1)
             if (m & 1u) acc = ERODE ? (acc & (bits >> j)) : (acc | (bits >> j));
@@ -270,25 +274,33 @@ __global__ __launch_bounds__(256) void tiled_morph_kernel(const uint8_t *__restr
     acc &= 0xffu;
     uint32_t o[2];
     if (ERODE) {
-        const uint8_t *cp = tile + (ly + a) * pitch + lx * 8 + s;
+        // border: rows < a or > H - a, columns < s or > W - s (imageAnalysis.cu:429)
+        if (row < a || row > H - a) acc = 0;
+        const int lo = s - col0, hi = W - s - col0;  // output i survives iff lo <= i <= hi
+        if (lo > 0) acc &= lo >= 8 ? 0u : (0xffu << lo);
+        if (hi < 7) acc &= hi < 0 ? 0u : ((1u << (hi + 1)) - 1u);
+        // the pixels themselves: 8 bytes at the output's own position (byte by byte at the image's end)
+        const int off = row * W + col0;
         uint32_t c0 = 0, c1 = 0;
+        if (off + 8 <= Ni) {
+            c0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
+            c1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4, 0, 0);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            c0 |= (uint32_t)cp[i] << (8 * i);
-            c1 |= (uint32_t)cp[4 + i] << (8 * i);
+            for (int i = 0; i < 4; i++) {
+                c0 |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, min(off + i, Ni), 0, 0) << (8 * i);
+                c1 |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, min(off + 4 + i, Ni), 0, 0) << (8 * i);
+            }
         }
         o[0] = c0 & spread4(acc & 0xfu);
         o[1] = c1 & spread4(acc >> 4);
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            if (is_border(row, col0 + i, W, H, a, s)) o[i >> 2] &= ~(0xffu << (8 * (i & 3)));
     } else {
         o[0] = spread4(acc & 0xfu);
         o[1] = spread4(acc >> 4);
     }
     uint8_t *q = dst + (long long)row * W + col0;
-    if (col0 + 8 <= W && ((reinterpret_cast<uintptr_t>(q) & 7u) == 0)) {
-        st8<true>(q, o[0], o[1]);
+    if (col0 + 8 <= W) {
+        st8_unaligned(q, o[0], o[1]);
     } else {
 #pragma unroll
         for (int i = 0; i < 8; i++)
@@ -310,13 +322,11 @@ static int launch_tiled_morph(const uint8_t *in, uint8_t *out, int W, int H, int
         }
     const int tiles_x = (W + TL_TW - 1) / TL_TW, tiles_y = (H + TL_TH - 1) / TL_TH;
     const dim3 grid((unsigned)(tiles_x * tiles_y), B);
-    const int pitch = ((TL_TW + kWe - 1 + 3) / 4) * 4 + 4;
-    const size_t lds = (size_t)(TL_TH + kHe - 1) * pitch + 16;
     if (erode)
-        hipLaunchKernelGGL((tiled_morph_kernel<true>), grid, dim3(256), lds, s, in, out, W, H, in_stride, out_stride, kWe, kHe,
+        hipLaunchKernelGGL((tiled_morph_kernel<true>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, kWe, kHe,
                            tiles_x, rows);
     else
-        hipLaunchKernelGGL((tiled_morph_kernel<false>), grid, dim3(256), lds, s, in, out, W, H, in_stride, out_stride, kWe, kHe,
+        hipLaunchKernelGGL((tiled_morph_kernel<false>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, kWe, kHe,
                            tiles_x, rows);
     IAK_LAUNCH_CHECK();
     return 0;
