@@ -245,32 +245,56 @@ struct Lin8Swar {
     }
 };
 
-// Sobel on 16-bit pairs: every instruction of the gradient part works on two pixels, and the
-// masks (imageAnalysis.cu:560-561) are applied separably -- horizontally once per input row,
-// vertically per output row:
+// Sobel on half-precision pairs: every instruction of the gradient part works on two pixels, and
+// the masks (imageAnalysis.cu:560-561) are applied separably -- horizontally once per input
+// row, vertically per output row:
 //   hd[j] = p[j+1] - p[j-1],  hs[j] = p[j-1] + 2 p[j] + p[j+1]      (per input row, kept)
 //   gx = hd(up) + 2 hd(mid) + hd(down),  gy = hs(down) - hs(up)
 // A row is unpacked to pairs in two alignments, O_k = (p[2k-1], p[2k]), E_k = (p[2k], p[2k+1])
 // (p[j] = pixel col0+j), so the +-1 column taps of the output pair (2k, 2k+1) are whole
 // registers: hd = O[k+1] - O[k], hs = O[k] + 2 E[k] + O[k+1].  Both responses are clamped to
 // [0,255] (linearFilter's clamp) before the magnitude (imageAnalysis.cu:552).
+//
+// The arithmetic is float16 on SUBNORMALS: a pixel byte b zero-extended to 16 bits is the
+// half-precision number b * 2^-24, so unpacking costs nothing, and every value here is an integer
+// of magnitude <= 1020 times 2^-24 -- exact in half precision (gradual underflow, 10-bit
+// mantissa).  The squares are summed in float32 by the two-term dot product, together with
+// 0.5 * 2^-48: y = sqrt(q + 0.5) * 2^-24 then lies at least 0.0006 inside (r, r + 1) for
+// r = floor(sqrt(q)), q <= 2 * 255^2, which the 1-ulp hardware square root cannot leave, and
+// the fused y * 2^24 + (2^23 - 0.5) -- the addend is exact, being below 2^23, while every sum
+// is above it, where floats are whole numbers -- rounds to 2^23 + r: the result's low mantissa
+// byte is (uchar)sqrtf(q).
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
 struct SobelRow {
-    s16x2 hd[4];
-    u16x2 hs[4];
+    h16x2 hd[4];
+    h16x2 hs[4];
 };
 
 struct Sobel8 {
     static const bool kBorderZero = true;
     typedef SobelRow Row;
-    __device__ __forceinline__ static u16x2 pr(uint32_t hi_src, uint32_t lo_src, uint32_t sel) {
-        return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi_src, lo_src, sel));
+    __device__ __forceinline__ static h16x2 pr(uint32_t hi_src, uint32_t lo_src, uint32_t sel) {
+        return __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(hi_src, lo_src, sel));
+    }
+    // min(x, top) and max(., 0) in one instruction: the clamp modifier bounds the result to [0, 1],
+    // and top is below 1
+    __device__ __forceinline__ static uint32_t min_clamp0(h16x2 x, h16x2 top) {
+        uint32_t r;
+        asm("v_pk_min_f16 %0, %1, %2 clamp" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, x)), "v"(__builtin_bit_cast(uint32_t, top)));
+        return r;
+    }
+    // g.x * g.x + g.y * g.y + c in float32; the three-address form keeps c in its register
+    __device__ __forceinline__ static float square2(h16x2 g, float c) {
+        float r;
+        asm("v_dot2_f32_f16 %0, %1, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, g)), "v"(c));
+        return r;
     }
     __device__ __forceinline__ void prepare(const Raw16 &q, int, int, int, int, SobelRow &r) const {
         // raw byte index = pixel + 4; selector 0x0c = zero byte, 0-3 = second source, 4-7 = first source
-        u16x2 o[5], e[4];
+        h16x2 o[5], e[4];
         o[0] = pr(q.d[1], q.d[0], 0x0c040c03u);  // p[-1], p[0]
         o[1] = pr(q.d[1], q.d[1], 0x0c020c01u);  // p[1], p[2]
         o[2] = pr(q.d[2], q.d[1], 0x0c040c03u);  // p[3], p[4]
@@ -280,27 +304,31 @@ struct Sobel8 {
         e[1] = pr(q.d[1], q.d[1], 0x0c030c02u);  // p[2], p[3]
         e[2] = pr(q.d[2], q.d[2], 0x0c010c00u);  // p[4], p[5]
         e[3] = pr(q.d[2], q.d[2], 0x0c030c02u);  // p[6], p[7]
+        const h16x2 two = {(_Float16)2, (_Float16)2};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            r.hd[k] = __builtin_bit_cast(s16x2, o[k + 1]) - __builtin_bit_cast(s16x2, o[k]);
-            r.hs[k] = o[k] + e[k] * (unsigned short)2 + o[k + 1];
+            r.hd[k] = o[k + 1] - o[k];
+            r.hs[k] = __builtin_elementwise_fma(e[k], two, o[k]) + o[k + 1];
         }
     }
     __device__ __forceinline__ void compute(const SobelRow &u, const SobelRow &m, const SobelRow &d, uint32_t o[2]) const {
-        const s16x2 zero = {0, 0}, top = {255, 255};
+        const h16x2 two = {(_Float16)2, (_Float16)2};
+        const h16x2 top = __builtin_bit_cast(h16x2, 0x00ff00ffu);  // 255 * 2^-24 twice
+        const float half_q = 0x1p-49f;                             // 0.5 in units of 2^-48
+        const float magic = 8388607.5f;                            // 2^23 - 0.5: one binade below the sums
         uint32_t res[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            s16x2 gx = u.hd[k] + m.hd[k] * (short)2 + d.hd[k];
-            s16x2 gy = __builtin_bit_cast(s16x2, d.hs[k]) - __builtin_bit_cast(s16x2, u.hs[k]);
-            gx = __builtin_elementwise_min(__builtin_elementwise_max(gx, zero), top);
-            gy = __builtin_elementwise_min(__builtin_elementwise_max(gy, zero), top);
-            const uint32_t GX = __builtin_bit_cast(uint32_t, gx), GY = __builtin_bit_cast(uint32_t, gy);
-            // (gx, gy) of one pixel side by side, then gx*gx + gy*gy in one dot product
-            const u16x2 g0 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(GY, GX, 0x05040100u));
-            const u16x2 g1 = __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(GY, GX, 0x07060302u));
-            res[2 * k] = isqrt_small(__builtin_amdgcn_udot2(g0, g0, 0u, false));
-            res[2 * k + 1] = isqrt_small(__builtin_amdgcn_udot2(g1, g1, 0u, false));
+            h16x2 gx = __builtin_elementwise_fma(m.hd[k], two, u.hd[k]) + d.hd[k];
+            h16x2 gy = d.hs[k] - u.hs[k];
+            const uint32_t GX = min_clamp0(gx, top), GY = min_clamp0(gy, top);
+            // (gx, gy) of one pixel side by side, then gx*gx + gy*gy + 0.5 in one dot product
+            const h16x2 g0 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(GY, GX, 0x05040100u));
+            const h16x2 g1 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(GY, GX, 0x07060302u));
+            const float y0 = __builtin_amdgcn_sqrtf(square2(g0, half_q));
+            const float y1 = __builtin_amdgcn_sqrtf(square2(g1, half_q));
+            res[2 * k] = __builtin_bit_cast(uint32_t, __builtin_fmaf(y0, 0x1p24f, magic));
+            res[2 * k + 1] = __builtin_bit_cast(uint32_t, __builtin_fmaf(y1, 0x1p24f, magic));
         }
         pack8(res, o);
     }

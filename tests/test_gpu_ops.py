@@ -342,6 +342,36 @@ def test_sobel_compass(ops, W, H, kind):
     each(ops.compassFilter, O.compass, imgs)
 
 
+def test_sobel_every_magnitude(ops):
+    """Every pair of clamped responses (gx, gy) a 3x3 window can produce -- equal parity, or one of them
+    clamped -- each in an isolated 3x3 cell on a 4-pixel pitch, so the square root is checked on every
+    sum of squares it can meet (imageAnalysis.cu:552)."""
+    cells = []  # (gx, gy, 3x3 values)
+    for gx in range(256):
+        for gy in range(gx & 1, 256, 2):
+            p = gx & 1
+            cells.append((gx, gy, [0, 0, 0, 0, 0, (gx - p) // 2, 0, (gy - p) // 2, p]))
+    for g in range(256):
+        z, y = g & 1, g >> 1
+        cells.append((255, g, [0, 0, 0, 0, 0, 200, 0, y, z]))      # gx clamped from above
+        cells.append((0, g, [0, 0, 0, 255, 0, 0, 0, y, z]))        # gx clamped from below
+        cells.append((g, 255, [0, 0, 0, 0, 0, y, 0, 200, z]))      # gy clamped from above
+        cells.append((g, 0, [0, 255, 0, 0, 0, y, 0, 0, z]))        # gy clamped from below
+    per_row = 256
+    rows = (len(cells) + per_row - 1) // per_row
+    img = np.zeros((4 * rows + 1, 4 * per_row), np.uint8)
+    want_centre = np.zeros((rows, per_row), np.uint8)
+    for i, (gx, gy, v) in enumerate(cells):
+        r, c = divmod(i, per_row)
+        img[4 * r + 1:4 * r + 4, 4 * c + 1:4 * c + 4] = np.array(v, np.uint8).reshape(3, 3)
+        want_centre[r, c] = int(np.floor(np.sqrt(float(gx * gx + gy * gy)))) & 255
+    got = ops.sobelFilter(dev(img)).cpu().numpy()
+    assert np.array_equal(got, O.sobel(img))
+    centre = got[2::4, 2::4][:rows]
+    flat = np.arange(rows * per_row).reshape(rows, per_row) < len(cells)
+    assert np.array_equal(centre[flat], want_centre[flat])
+
+
 SES = {
     "ones3": (3, 3, [1] * 9),
     "cross3": (3, 3, [0, 1, 0, 1, 1, 1, 0, 1, 0]),
