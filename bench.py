@@ -44,7 +44,7 @@ P_A = [
 KERNEL_OF_GROUP = {
     "gray+hist": "iak::gray_kernel<0, true>",
     "equalize+gauss+salt_pepper+linear+median+sobel": "iak::strip_kernel",
-    "equalize+gauss+salt_pepper+linear": "iak::chain_stencil8_kernel<iak::Lin8Swar>",
+    "equalize+gauss+salt_pepper+linear": "iak::chain_stencil8_flat_kernel<iak::Lin8Swar>",
     "equalize+gauss+salt_pepper": "iak::chain_apply_kernel<false>",
     "linear": "iak::stencil8_kernel<iak::Lin8Swar, 8, false, false>",
     "median": "iak::stencil8_kernel<iak::Median8, 8, false, false>",

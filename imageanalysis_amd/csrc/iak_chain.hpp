@@ -13,7 +13,8 @@ enum { C_EQUALIZE = 1, C_OTSU = 2, C_CONST_LUT = 3, C_GAUSS = 4, C_SP = 5, C_KME
 struct ChainStage {
     int type;
     float mean, stddev;    // C_GAUSS
-    const uint8_t *plane;  // C_GAUSS: rv plane, C_SP: code plane, C_KMEANS: int32 initial centroids [B][2]
+    const uint8_t *plane;  // C_GAUSS: rv plane, C_SP: keep-mask plane, C_KMEANS: int32 initial centroids [B][2]
+    const uint8_t *plane2; // C_SP: salt-mask plane
     int lut_slot;          // C_CONST_LUT: index into ChainDesc::const_lut
 };
 struct ChainDesc {
@@ -57,13 +58,23 @@ __device__ __forceinline__ uint32_t addbytes(uint32_t a, uint32_t n) {
     return ((a & 0x7f7f7f7fu) + (n & 0x7f7f7f7fu)) ^ ((a ^ n) & 0x80808080u);
 }
 
+// bit s = stage s is a Gaussian stage whose table holds NaN amplitudes; uniform over the
+// workgroup, read once after chain_load_tables so the per-chunk code tests a scalar
+__device__ __forceinline__ uint32_t chain_nan_bits(const ChainTables &t) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int s = 0; s < CHAIN_MAX; s++) bits |= t.any_nan[s] ? (1u << s) : 0u;
+    return __builtin_amdgcn_readfirstlane(bits);
+}
+
 // the whole chain on 16 pixels whose flat offset in the image is `off` (16-byte aligned planes)
-__device__ __forceinline__ u32x4 chain_apply16(u32x4 v, long long off, const ChainDesc &d, const ChainTables &t) {
+__device__ __forceinline__ u32x4 chain_apply16(u32x4 v, long long off, const ChainDesc &d, const ChainTables &t,
+                                               uint32_t nan_bits) {
     for (int s = 0; s < d.n; s++) {
         const int type = d.st[s].type;
         if (type == C_GAUSS) {
             const u32x4 r = ld16(d.st[s].plane + off);
-            if (t.any_nan[s]) {  // degenerate variance: rare, uniform per image
+            if ((nan_bits >> s) & 1u) {  // degenerate variance: rare, uniform per image
 #pragma unroll
                 for (int w = 0; w < 4; w++) v[w] = addbytes(v[w], lookup4(t.lut[s], r[w])) & ~lookup4(t.nanf[s], r[w]);
             } else {
@@ -71,9 +82,11 @@ __device__ __forceinline__ u32x4 chain_apply16(u32x4 v, long long off, const Cha
                 for (int w = 0; w < 4; w++) v[w] = addbytes(v[w], lookup4(t.lut[s], r[w]));
             }
         } else if (type == C_SP) {
-            const u32x4 c = ld16(d.st[s].plane + off);
+            // salt and pepper as two byte masks (0x00 / 0xff): one three-input logic op per four pixels
+            const u32x4 keep = ld16(d.st[s].plane + off);
+            const u32x4 salt = ld16(d.st[s].plane2 + off);
 #pragma unroll
-            for (int w = 0; w < 4; w++) v[w] = sp4(v[w], c[w]);
+            for (int w = 0; w < 4; w++) v[w] = (v[w] & keep[w]) | salt[w];
         } else {
 #pragma unroll
             for (int w = 0; w < 4; w++) v[w] = lookup4(t.lut[s], v[w]);
@@ -90,8 +103,7 @@ __device__ __forceinline__ uint32_t chain_apply1(uint32_t p, long long off, cons
             const uint32_t r = d.st[s].plane[off];
             p = t.nanf[s][r] ? 0u : ((p + t.lut[s][r]) & 0xffu);
         } else if (type == C_SP) {
-            const uint32_t c = d.st[s].plane[off];
-            p = c == 0 ? p : (c == 2 ? 255u : 0u);
+            p = (p & d.st[s].plane[off]) | d.st[s].plane2[off];
         } else {
             p = t.lut[s][p];
         }

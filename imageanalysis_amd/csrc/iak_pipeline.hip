@@ -130,6 +130,16 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *hist_in
     if (hist_out) hist_out[(long long)b * 256 + v] = h[v];
 }
 
+// salt-and-pepper code plane (0 keep, 1 pepper, 2 salt) -> the two byte masks of (pixel & keep) | salt
+__global__ __launch_bounds__(256) void sp_masks_kernel(const uint8_t *__restrict__ code, uint8_t *__restrict__ keep,
+                                                       uint8_t *__restrict__ salt, long long N) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint8_t c = code[i];
+    keep[i] = c == 0 ? 0xff : 0x00;
+    salt[i] = c == 2 ? 0xff : 0x00;
+}
+
 // HIST: also accumulates the histogram of the output (hist[b][256], zeroed by the launcher, bin 0
 // left empty), for the consumer behind this run.
 template <bool HIST = false>
@@ -143,6 +153,7 @@ __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restr
     if (HIST) hist_zero(sh);
     const int b = blockIdx.y;
     chain_load_tables(t, d, tables + (long long)b * CHAIN_MAX * 256);
+    const uint32_t nan_bits = chain_nan_bits(t);
     const uint8_t *src = in + (long long)b * in_stride;
     uint8_t *dst = out + (long long)b * out_stride;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,8 +168,8 @@ __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restr
             const long long off1 = two ? ((c + nthreads) << 4) : off0;
             const u32x4 v0 = ld16<IAK_NT_CHAIN_LD>(src + off0);
             const u32x4 v1 = ld16<IAK_NT_CHAIN_LD>(src + off1);
-            const u32x4 y0 = chain_apply16(v0, off0, d, t);
-            const u32x4 y1 = chain_apply16(v1, off1, d, t);
+            const u32x4 y0 = chain_apply16(v0, off0, d, t, nan_bits);
+            const u32x4 y1 = chain_apply16(v1, off1, d, t, nan_bits);
             st16<IAK_NT_CHAIN_ST>(dst + off0, y0);
             if (two) st16<IAK_NT_CHAIN_ST>(dst + off1, y1);
             if (HIST) {
@@ -300,7 +311,10 @@ struct iak_pipeline {
     uint8_t *feat_ws = nullptr;
     long long feat_ws_per_image = 0;
     float *features_out = nullptr;
-    std::vector<std::pair<int, uint8_t *>> sp;  // level -> plane
+    // level -> planes: the code plane (0 keep, 1 pepper, 2 salt) followed, plane_pitch bytes apart,
+    // by the keep-mask and salt-mask planes the fused chain passes read
+    std::vector<std::pair<int, uint8_t *>> sp;
+    long long plane_pitch = 0;
     // concurrency: the batch is cut into `lanes` sub-batches that run on their own streams, so
     // that bandwidth-bound and issue-bound kernels of different sub-batches overlap
     int lanes = 1;
@@ -455,7 +469,8 @@ static int plan(iak_pipeline *p) {
                     break;
                 case IAK_OP_SALT_PEPPER:
                     st.type = C_SP;
-                    st.plane = p->sp_plane(q.iparam);
+                    st.plane = p->sp_plane(q.iparam) + p->plane_pitch;
+                    st.plane2 = st.plane + p->plane_pitch;
                     break;
                 }
                 g.chain.st[g.chain.n++] = st;
@@ -687,9 +702,15 @@ int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op
         for (auto &c : p->ops)
             if (rc == 0 && c.op.type == IAK_OP_SALT_PEPPER && !p->sp_plane(c.op.iparam)) {
                 uint8_t *pl = nullptr;
-                TRY(hipMalloc((void **)&pl, (size_t)p->N));
+                p->plane_pitch = (p->N + 255) & ~255LL;
+                TRY(hipMalloc((void **)&pl, 3 * (size_t)p->plane_pitch));
                 p->sp.emplace_back(c.op.iparam, pl);
                 rc = iak_sp_plane(p->x0, p->x1, pl, p->N, c.op.iparam, nullptr);
+                if (rc == 0) {
+                    hipLaunchKernelGGL(sp_masks_kernel, dim3((unsigned)((p->N + 255) / 256)), dim3(256), 0, nullptr, pl,
+                                       pl + p->plane_pitch, pl + 2 * p->plane_pitch, p->N);
+                    rc = (int)hipGetLastError();
+                }
             }
         if (rc == 0) rc = (int)hipStreamSynchronize(nullptr);
         if (rc != 0) { free_all(p); delete p; return rc; }

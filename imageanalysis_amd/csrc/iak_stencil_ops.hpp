@@ -286,12 +286,6 @@ struct Sobel8 {
         asm("v_pk_min_f16 %0, %1, %2 clamp" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, x)), "v"(__builtin_bit_cast(uint32_t, top)));
         return r;
     }
-    // g.x * g.x + g.y * g.y + c in float32; the three-address form keeps c in its register
-    __device__ __forceinline__ static float square2(h16x2 g, float c) {
-        float r;
-        asm("v_dot2_f32_f16 %0, %1, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(uint32_t, g)), "v"(c));
-        return r;
-    }
     __device__ __forceinline__ void prepare(const Raw16 &q, int, int, int, int, SobelRow &r) const {
         // raw byte index = pixel + 4; selector 0x0c = zero byte, 0-3 = second source, 4-7 = first source
         h16x2 o[5], e[4];
@@ -314,7 +308,13 @@ struct Sobel8 {
     __device__ __forceinline__ void compute(const SobelRow &u, const SobelRow &m, const SobelRow &d, uint32_t o[2]) const {
         const h16x2 two = {(_Float16)2, (_Float16)2};
         const h16x2 top = __builtin_bit_cast(h16x2, 0x00ff00ffu);  // 255 * 2^-24 twice
-        const float half_q = 0x1p-49f;                             // 0.5 in units of 2^-48
+        // 0.5 in units of 2^-48.  The empty asm hides the constant from the compiler, which otherwise
+        // re-creates it with a move in front of every dot product (the two-address form overwrites
+        // its addend); as a live register it is used in the three-address form.  The dot products stay
+        // compiler-generated: the wait states this chip needs between a dot product and the instruction
+        // that reads its result are the compiler's to insert, and it cannot see into asm text.
+        float half_q = 0x1p-49f;
+        asm("" : "+v"(half_q));
         const float magic = 8388607.5f;                            // 2^23 - 0.5: one binade below the sums
         uint32_t res[8];
 #pragma unroll
@@ -325,8 +325,8 @@ struct Sobel8 {
             // (gx, gy) of one pixel side by side, then gx*gx + gy*gy + 0.5 in one dot product
             const h16x2 g0 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(GY, GX, 0x05040100u));
             const h16x2 g1 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(GY, GX, 0x07060302u));
-            const float y0 = __builtin_amdgcn_sqrtf(square2(g0, half_q));
-            const float y1 = __builtin_amdgcn_sqrtf(square2(g1, half_q));
+            const float y0 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fdot2(g0, g0, half_q, false));
+            const float y1 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fdot2(g1, g1, half_q, false));
             res[2 * k] = __builtin_bit_cast(uint32_t, __builtin_fmaf(y0, 0x1p24f, magic));
             res[2 * k + 1] = __builtin_bit_cast(uint32_t, __builtin_fmaf(y1, 0x1p24f, magic));
         }

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(SK_THREADS) void strip_kernel(const uint8_t *__rest
     uint8_t *dst = out + (long long)b * out_stride;
     const long long N = (long long)W * H;
     if (d.n) chain_load_tables(t, d, tables + (long long)b * CHAIN_MAX * 256);
+    const uint32_t nan_bits = d.n ? chain_nan_bits(t) : 0u;
 
     // stage the strip: rows y0-S .. y0+TH+S-1 plus 16 bytes on either side, chain applied
     const long long flat0 = (long long)(y0 - S) * W - 16;
@@ -187,8 +188,8 @@ __global__ __launch_bounds__(SK_THREADS) void strip_kernel(const uint8_t *__rest
         u32x4 v0 = ld16<IAK_NT_CHAIN_LD>(src + g0);
         u32x4 v1 = ld16<IAK_NT_CHAIN_LD>(src + g1);
         if (d.n) {
-            v0 = chain_apply16(v0, g0, d, t);
-            v1 = chain_apply16(v1, g1, d, t);
+            v0 = chain_apply16(v0, g0, d, t, nan_bits);
+            v1 = chain_apply16(v1, g1, d, t, nan_bits);
         }
         const u32x4 zero = {0, 0, 0, 0};
         *reinterpret_cast<u32x4 *>(bufA + 16 * c) = ok0 ? v0 : zero;
