@@ -129,8 +129,9 @@ __global__ __launch_bounds__(CS_THREADS) void chain_stencil8_flat_kernel(const u
     // is wholly inside or outside the image; outside is staged as 0)
     const int nchunks = tile_bytes >> 4;
     const int fbase = (y0 - 1) * W - 16;
-    for (int c = threadIdx.x; c < nchunks; c += 2 * CS_THREADS) {
-        const int c1 = c + CS_THREADS;
+    const int T = blockDim.x;  // 512, or 256 for the operators that need many registers (see the launcher)
+    for (int c = threadIdx.x; c < nchunks; c += 2 * T) {
+        const int c1 = c + T;
         const int f0 = fbase + 16 * c, f1 = fbase + 16 * c1;
         const bool in1 = c1 < nchunks;
         const bool ok0 = f0 >= 0 && f0 < Ni;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(CS_THREADS) void chain_stencil8_flat_kernel(const u
     // phase 2: the stencil on 8-pixel chunks x groups of 8 rows, rows coming from the tile
     const int cols = W >> 3;
     const int items = cols * (TH >> 3);
-    for (int it = threadIdx.x; it < items; it += CS_THREADS) {
+    for (int it = threadIdx.x; it < items; it += T) {
         const int rg = it / cols, cx = it - rg * cols;
         const int col0 = cx << 3;
         const int yb = y0 + (rg << 3);
@@ -224,9 +225,12 @@ static int launch_chain_stencil(const uint8_t *in, uint8_t *out, int W, int H, i
                                 long long out_stride, const ChainDesc &d, const uint16_t *tables, const Op &op,
                                 hipStream_t s) {
     const TileGeom g = tile_geometry(W, H);
+    // An operator that needs more than 64 registers per lane leaves room for one 512-lane workgroup
+    // per CU, whose two phases then run one after the other with nothing to overlap them; as 256-lane
+    // workgroups the same number of waves belongs to four workgroups in different phases.
     if (g.flat)
-        hipLaunchKernelGGL((chain_stencil8_flat_kernel<Op>), dim3(g.tiles_y, B), dim3(CS_THREADS), g.lds, s, in, out, W, H,
-                           in_stride, out_stride, d, tables, g.TH, op);
+        hipLaunchKernelGGL((chain_stencil8_flat_kernel<Op>), dim3(g.tiles_y, B), dim3(Op::kManyRegisters ? 256 : CS_THREADS),
+                           g.lds, s, in, out, W, H, in_stride, out_stride, d, tables, g.TH, op);
     else
         hipLaunchKernelGGL((chain_stencil8_kernel<Op>), dim3(g.tiles_x * g.tiles_y, B), dim3(CS_THREADS), g.lds, s, in, out, W, H,
                            in_stride, out_stride, d, tables, g.TW, g.TH, g.tiles_x, op);

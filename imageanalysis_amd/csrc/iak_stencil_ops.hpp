@@ -7,6 +7,7 @@
 //   void compute(const Row& up, const Row& mid, const Row& dn, uint32_t o[2])   8 output pixels
 //   static const bool kBorderZero   false only for dilation (its border pixels can be reached
 //                                   by a neighbour's window)
+//   static const bool kManyRegisters  the fused kernel needs more than 64 registers per lane with it
 // Raw16 holds bytes col0-4 .. col0+11 of one image row on the FLAT view of the image
 // (imageAnalysis.cu:514-521: taps are read at i*W+j, so the pixel after a row's last one is
 // the next row's first; flat indices outside the image read 0).
@@ -123,6 +124,7 @@ struct FRow8 {
 template <bool AVERAGE>
 struct Lin8Float {
     static const bool kBorderZero = true;
+    static const bool kManyRegisters = true;
     typedef FRow8 Row;
     float k[9];
     __device__ __forceinline__ void prepare(const Raw16 &q, int, int, int, int, FRow8 &f) const {
@@ -161,6 +163,7 @@ struct Lin8Float {
 template <bool AVERAGE>
 struct Lin8Int : Unpacked8 {
     static const bool kBorderZero = true;
+    static const bool kManyRegisters = false;
     int k[9];
     __device__ __forceinline__ void compute(const PRow &u, const PRow &m, const PRow &d, uint32_t o[2]) const {
         int res[8];
@@ -188,6 +191,7 @@ struct Lin8Int : Unpacked8 {
 template <bool AVERAGE>
 struct Lin8Fixed : Unpacked8 {
     static const bool kBorderZero = true;
+    static const bool kManyRegisters = false;
     uint32_t k[9];  // weight * 2^q
     int q;
     __device__ __forceinline__ void compute(const PRow &u, const PRow &m, const PRow &d, uint32_t o[2]) const {
@@ -219,6 +223,7 @@ struct SwarRow {
 
 struct Lin8Swar {
     static const bool kBorderZero = true;
+    static const bool kManyRegisters = false;
     typedef SwarRow Row;
     int sa, sb, sc;            // shifts; 8 means the weight is zero
     __device__ __forceinline__ static uint32_t plane(uint32_t x, int s) {
@@ -275,6 +280,7 @@ struct SobelRow {
 
 struct Sobel8 {
     static const bool kBorderZero = true;
+    static const bool kManyRegisters = true;
     typedef SobelRow Row;
     __device__ __forceinline__ static h16x2 pr(uint32_t hi_src, uint32_t lo_src, uint32_t sel) {
         return __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(hi_src, lo_src, sel));
@@ -351,6 +357,7 @@ struct CompassRow {
 
 struct Compass8 {
     static const bool kBorderZero = true;
+    static const bool kManyRegisters = true;
     typedef CompassRow Row;
     __device__ __forceinline__ static s16x2 pr(uint32_t hi_src, uint32_t lo_src, uint32_t sel) {
         return __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(hi_src, lo_src, sel));
@@ -407,6 +414,7 @@ struct PkRow {
 template <bool AVERAGE>
 struct Lin8Pk16 {
     static const bool kBorderZero = true;
+    static const bool kManyRegisters = false;
     typedef PkRow Row;
     s16x2 k[9];  // each weight in both halves
     __device__ __forceinline__ static s16x2 pr(uint32_t hi_src, uint32_t lo_src, uint32_t sel) {
@@ -461,6 +469,7 @@ struct Lin8Pk16 {
 // highs, and the median of those.
 struct Median8 : Unpacked8 {
     static const bool kBorderZero = true;
+    static const bool kManyRegisters = true;
     __device__ __forceinline__ void compute(const PRow &u, const PRow &m, const PRow &d, uint32_t o[2]) const {
         uint32_t lo[10], md[10], hi[10];
 #pragma unroll
@@ -485,6 +494,7 @@ struct Median8 : Unpacked8 {
 // sorted window (imageAnalysis.cu:653-677).
 struct WMedian8 : Unpacked8 {
     static const bool kBorderZero = true;
+    static const bool kManyRegisters = true;
     uint32_t w[9];
     uint32_t rank;  // kernSum / 2
     __device__ __forceinline__ static void ce(uint32_t &a, uint32_t &b) {
@@ -531,6 +541,7 @@ __device__ __forceinline__ uint32_t row_bits8(const Raw16 &q) {
 
 struct Erode8 {
     static const bool kBorderZero = true;
+    static const bool kManyRegisters = false;
     typedef MRow8 Row;
     uint32_t mask;  // bit n set: structuring element n is non-zero
     __device__ __forceinline__ void prepare(const Raw16 &q, int, int, int, int, MRow8 &r) const {
@@ -557,6 +568,7 @@ struct Erode8 {
 
 struct Dilate8 {
     static const bool kBorderZero = false;
+    static const bool kManyRegisters = false;
     typedef MRow8 Row;
     uint32_t mask;
     // Source pixels are those that scatter in the reference: foreground and not on the border
