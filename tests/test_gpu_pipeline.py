@@ -123,7 +123,7 @@ def Pipeline():
 @pytest.mark.parametrize("name", list(CHAINS))
 @pytest.mark.parametrize("fused", [False, "pointwise", True, "strips"])
 @pytest.mark.parametrize("W,H,kind", [(64, 48, "C"), (37, 23, "U"), (768, 40, "C"), (48, 203, "U"), (1056, 21, "U"),
-                                      (16, 9, "U"), (2048, 5, "C"), (8, 11, "U"), (40, 8, "C")])
+                                      (16, 9, "U"), (1024, 43, "U"), (2048, 5, "C"), (8, 11, "U"), (40, 8, "C")])
 def test_pipeline_matches_oracle(Pipeline, name, fused, W, H, kind):
     ops = CHAINS[name]
     B = 3
