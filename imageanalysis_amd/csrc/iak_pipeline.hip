@@ -166,10 +166,9 @@ __global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restr
             const long long off0 = c << 4;
             const bool two = c + nthreads < nchunks;
             const long long off1 = two ? ((c + nthreads) << 4) : off0;
-            const u32x4 v0 = ld16<IAK_NT_CHAIN_LD>(src + off0);
-            const u32x4 v1 = ld16<IAK_NT_CHAIN_LD>(src + off1);
-            const u32x4 y0 = chain_apply16(v0, off0, d, t, nan_bits);
-            const u32x4 y1 = chain_apply16(v1, off1, d, t, nan_bits);
+            u32x4 y0 = ld16<IAK_NT_CHAIN_LD>(src + off0);
+            u32x4 y1 = ld16<IAK_NT_CHAIN_LD>(src + off1);
+            chain_apply16x2(y0, y1, off0, off1, d, t, nan_bits);
             st16<IAK_NT_CHAIN_ST>(dst + off0, y0);
             if (two) st16<IAK_NT_CHAIN_ST>(dst + off1, y1);
             if (HIST) {
