@@ -18,11 +18,23 @@
 #include "iak_common.hpp"
 
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace iak {
 
 #define FEAT_N 7
+
+// Scratch of iak_features_static: per image a 256-bin histogram, an edge counter and a
+// threshold.  One copy per GPU, held until the process ends; host code reaches it only through
+// the per-device address that features_static_scratch() looks up.
+#define FEAT_STATIC_MAX_IMAGES 1024
+struct FeatStaticScratch {
+    uint32_t hist[FEAT_STATIC_MAX_IMAGES * 256];
+    uint32_t counts[FEAT_STATIC_MAX_IMAGES];
+    int32_t thr[FEAT_STATIC_MAX_IMAGES];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(FeatStaticScratch)];
 
 // One workgroup of 256 lanes per image, lane v = grey value v.
 // features[b] = {mean, std, area, (perimeter: later), mode, rangeMin, rangeMax};
@@ -329,6 +341,32 @@ long long iak_features_workspace_bytes(int W, int H, int B) {
     return bytes;
 }
 
+// The one-pass form (W % 16 == 0): statistics from the histogram, the perimeter from one read of
+// the image on bit masks.  own_hist / counts / thr: scratch for B images.
+static int features_one_pass(const uint8_t *img, int W, int H, int B, long long stride, const uint32_t *hist, float *features,
+                             uint32_t *own_hist, uint32_t *counts, int32_t *thr, void *stream) {
+    const long long N = (long long)W * H;
+    if ((reinterpret_cast<uintptr_t>(img) & 3u) || stride % 4 != 0) return IAK_E_UNSUPPORTED;
+    hipStream_t s = as_stream(stream);
+    int rc;
+    if (!hist) {
+        if ((rc = iak_hist(img, own_hist, N, B, stride, stream))) return rc;
+        hist = own_hist;
+    }
+    // also clears counts[0..B)
+    hipLaunchKernelGGL(features_stats_kernel, dim3(B), dim3(256), 0, s, hist, (int)N, B, features, counts, thr);
+    IAK_LAUNCH_CHECK();
+    static const CompassLut lut = make_compass_lut();
+    const long long items = (long long)(W >> 3) * ((H + 7) / 8);
+    hipLaunchKernelGGL(perimeter_bits_kernel, dim3(blocks_x(items, 256, B, 1 << 20), B), dim3(256), 0, s, img, W, H, stride,
+                       thr, counts, lut);
+    IAK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(features_perimeter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, counts, (const uint32_t *)nullptr,
+                       features, B);
+    IAK_LAUNCH_CHECK();
+    return 0;
+}
+
 int iak_features(const uint8_t *img, int W, int H, int B, long long stride, const uint32_t *hist, float *features,
                  void *workspace, void *stream) {
     if (!img || !features || !workspace || W <= 0 || H <= 0 || B <= 0) return IAK_E_ARG;
@@ -342,6 +380,8 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
     int32_t *thr = reinterpret_cast<int32_t *>(counts + B);
     size_t head = (size_t)B * 256 * 4 + (size_t)B * CHAIN_MAX * 256 * 2 + (size_t)B * 8;
     head = (head + 255) & ~(size_t)255;
+    // the workspace for a W % 16 == 0 shape holds no image buffers: the one-pass form is the only one
+    if (W % 16 == 0 && N < (1LL << 30)) return features_one_pass(img, W, H, B, stride, hist, features, own_hist, counts, thr, stream);
     int rc;
     if (!hist) {
         if ((rc = iak_hist(img, own_hist, N, B, stride, stream))) return rc;
@@ -349,29 +389,53 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
     }
     hipLaunchKernelGGL(features_stats_kernel, dim3(B), dim3(256), 0, s, hist, (int)N, B, features, counts, thr);
     IAK_LAUNCH_CHECK();
-    if (W % 16 == 0 && N < (1LL << 30)) {
-        // the workspace for this shape holds no image buffers: the one-pass form is the only one
-        if ((reinterpret_cast<uintptr_t>(img) & 3u) || stride % 4 != 0) return IAK_E_UNSUPPORTED;
-        static const CompassLut lut = make_compass_lut();
-        const long long items = (long long)(W >> 3) * ((H + 7) / 8);
-        hipLaunchKernelGGL(perimeter_bits_kernel, dim3(blocks_x(items, 256, B, 1 << 20), B), dim3(256), 0, s, img, W, H, stride,
-                           thr, counts, lut);
-        IAK_LAUNCH_CHECK();
-        hipLaunchKernelGGL(features_perimeter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, counts, (const uint32_t *)nullptr,
-                           features, B);
-    } else {
-        // any other shape: the three passes of the reference, on workspace images
-        const size_t img_bytes = ((size_t)B * (size_t)N + 255) & ~(size_t)255;
-        uint8_t *mask = ws + head, *edges = mask + img_bytes;
-        uint32_t *edge_hist = reinterpret_cast<uint32_t *>(edges + img_bytes);
-        if ((rc = iak_threshold_per_image(img, mask, N, B, stride, N, thr, stream))) return rc;
-        if ((rc = iak_compass(mask, edges, W, H, B, N, N, stream))) return rc;
-        if ((rc = iak_hist(edges, edge_hist, N, B, N, stream))) return rc;
-        hipLaunchKernelGGL(features_perimeter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const uint32_t *)nullptr,
-                           edge_hist, features, B);
-    }
+    // any other shape: the three passes of the reference, on workspace images
+    const size_t img_bytes = ((size_t)B * (size_t)N + 255) & ~(size_t)255;
+    uint8_t *mask = ws + head, *edges = mask + img_bytes;
+    uint32_t *edge_hist = reinterpret_cast<uint32_t *>(edges + img_bytes);
+    if ((rc = iak_threshold_per_image(img, mask, N, B, stride, N, thr, stream))) return rc;
+    if ((rc = iak_compass(mask, edges, W, H, B, N, N, stream))) return rc;
+    if ((rc = iak_hist(edges, edge_hist, N, B, N, stream))) return rc;
+    hipLaunchKernelGGL(features_perimeter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const uint32_t *)nullptr,
+                       edge_hist, features, B);
     IAK_LAUNCH_CHECK();
     return 0;
+}
+
+// Address of this device's copy of `scratch`.  The array's name is only a host-side handle for
+// hipGetSymbolAddress; every GPU has its own copy at its own address, looked up once per device
+// with that device current.
+#define FEAT_STATIC_MAX_DEVICES 64
+static int features_static_scratch(FeatStaticScratch **out) {
+    static std::mutex mu;
+    static FeatStaticScratch *ptr_of_device[FEAT_STATIC_MAX_DEVICES];
+    int dev = -1;
+    IAK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= FEAT_STATIC_MAX_DEVICES) return IAK_E_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr_of_device[dev]) {
+        void *p = nullptr;
+        IAK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return IAK_E_UNSUPPORTED;
+        ptr_of_device[dev] = static_cast<FeatStaticScratch *>(p);
+    }
+    *out = ptr_of_device[dev];
+    return 0;
+}
+
+int iak_features_static_max_images(void) { return FEAT_STATIC_MAX_IMAGES; }
+
+int iak_features_static(const uint8_t *img, int W, int H, int B, long long stride, const uint32_t *hist, float *features,
+                        void *stream) {
+    if (!img || !features || W <= 0 || H <= 0 || B <= 0) return IAK_E_ARG;
+    const long long N = (long long)W * H;
+    if (stride < N || N >= (1LL << 31)) return IAK_E_ARG;
+    if (W % 16 != 0 || N >= (1LL << 30)) return IAK_E_UNSUPPORTED;  // the other shapes need image-sized scratch
+    if (B > FEAT_STATIC_MAX_IMAGES) return IAK_E_TOO_LARGE;
+    FeatStaticScratch *sc = nullptr;
+    const int rc = features_static_scratch(&sc);
+    if (rc) return rc;
+    return features_one_pass(img, W, H, B, stride, hist, features, sc->hist, sc->counts, sc->thr, stream);
 }
 
 int iak_kmeans2_map(const uint32_t *hist, int numPixels, int B, const int32_t *init_centroids, int32_t *map,

@@ -64,6 +64,8 @@ SIGNATURES = {
     "iak_erode": [_vp, _vp, _i, _i, _i, _ll, _ll, _vp, _i, _i, _vp],
     "iak_features_workspace_bytes": [_i, _i, _i],
     "iak_features": [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp],
+    "iak_features_static_max_images": [],
+    "iak_features_static": [_vp, _i, _i, _i, _ll, _vp, _vp, _vp],
     "iak_kmeans2_map": [_vp, _i, _i, _vp, _vp, _vp, _vp],
     "iak_glibc_rand_seed": [_vp, C.c_uint, _vp],
     "iak_glibc_rand_centroids": [_vp, _i, _i, _vp, _vp],

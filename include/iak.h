@@ -184,6 +184,20 @@ int iak_erode(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in
 long long iak_features_workspace_bytes(int W, int H, int B);
 int iak_features(const uint8_t *img, int W, int H, int B, long long stride, const uint32_t *hist,
                  float *features, void *workspace, void *stream);
+/* iak_features without a workspace argument and without any allocation.  It has no counterpart in
+ * the reference: it is for callers that cannot allocate device memory or carry a workspace --
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
+ * results as iak_features.  Its scratch (per image: a 256-bin histogram, an edge counter, a
+ * threshold; about 1 MiB) is a fixed array inside the library, one copy per GPU, held until the
+ * process ends.  Limits: B <= iak_features_static_max_images() (1024; more returns
+ * IAK_E_TOO_LARGE), W % 16 == 0 and 4-byte aligned images and stride (IAK_E_UNSUPPORTED otherwise:
+ * the other shapes need image-sized scratch).  Every call on a GPU uses that GPU's one array, so
+ * calls that overlap on one GPU (different streams, different host threads) race; calls on one
+ * stream, or on streams ordered after one another, are fine.  Run it with the device current
+ * whose memory img / features live in. */
+int iak_features_static_max_images(void);
+int iak_features_static(const uint8_t *img, int W, int H, int B, long long stride, const uint32_t *hist,
+                        float *features, void *stream);
 /* kMeansThresholding (imageAnalysis.cu:281-379; k = 2) on histograms: map[b][v] = 0 or 255, the
  * value applyLabels (:339-349) gives a pixel of value v; apply it with iak_apply_map.
  * init_centroids: DEVICE int32[B][2], the two random(0,256) draws of each image (:359-361).
