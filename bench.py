@@ -3,24 +3,88 @@
 equalise -> Gaussian noise -> salt-and-pepper -> 3x3 linear -> 3x3 median -> Sobel) on a
 device-resident batch of synthetic 768x568 cell-like images, through the C ABI's batched
 executor.  One process per GPU; images shard image-wise (every rank owns a full batch,
-weak scaling); the only collective is one all-reduce of the 256-bin dataset histogram per
-step.
+weak scaling); the only collective is one all-reduce of the dataset-level sums per step
+(the 256-bin histogram; with feature extraction also the per-class feature statistics).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+With --gpus N > 1 and no RANK in the environment the first form starts the second one itself,
+as a child process, relays rank 0's line and exits with the child's status.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
+    ap.add_argument("--workload", default="P-A", choices=["P-A", "P-B", "P-C"])
+    ap.add_argument("--linear-kernel", default="binomial16", choices=["binomial16", "config"],
+                    help="P-A's 3x3 linear filter: the binomial [1,2,1;2,4,2;1,2,1]/16 or the reference configuration's "
+                         "[1,1,1,10,1,1,1,1,1] (test/configs/input.json:43-53)")
+    ap.add_argument("--stagewise", action="store_true", help="one pass per operation (no fusion)")
+    ap.add_argument("--pointwise", action="store_true", help="fuse per-pixel runs only; stencils stay separate passes")
+    ap.add_argument("--strips", action="store_true", help="also fuse runs of 3x3 stencils through LDS strips")
+    ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per GPU (executor streams)")
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="run the pipeline untimed for this long before the warm-up steps (clock ramp after the idle "
+                         "gap of input generation); 0 disables")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the all-reduce path even with one rank (self-test of the multi-GPU path)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N ranks that all use GPU 0 and reduce over gloo: exercises the launch, sharding and reduction "
+                         "code on a one-GPU machine.  The line it prints is marked as a rehearsal, not a measurement")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="default P-A run only: skip the short P-B / P-C / configuration-kernel measurements")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel events in the timed steps (no roofline)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """Start `--gpus` ranks of this script under torch.distributed.run as a CHILD process (this
+    process has not touched the GPU: torch is not even imported yet), pass rank 0's JSON line
+    through and return the child's exit status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        if line.lstrip().startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return proc.wait()
+
+
+if __name__ == "__main__":
+    _early = parse_args()
+    if _early.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(_early, sys.argv[1:]))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
@@ -29,17 +93,27 @@ from imageanalysis_amd.pipeline import Pipeline  # noqa: E402
 
 W, H = 768, 568
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+# instruction issue: 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 clocks per SIMD
+N_SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 GAUSS16 = [1 / 16, 2 / 16, 1 / 16, 2 / 16, 4 / 16, 2 / 16, 1 / 16, 2 / 16, 1 / 16]
+CONFIG_KERNEL = [1.0, 1.0, 1.0, 10.0, 1.0, 1.0, 1.0, 1.0, 1.0]  # test/configs/input.json:43-53
 OP_EQUALIZE, OP_GAUSS, OP_SP, OP_LINEAR, OP_MEDIAN, OP_SOBEL = 1, 2, 3, 4, 6, 7
-P_A = [
-    {"type": OP_EQUALIZE},
-    {"type": OP_GAUSS, "mean": -1.0, "stddev": -1.0},
-    {"type": OP_SP, "iparam": 50},
-    {"type": OP_LINEAR, "kW": 3, "kH": 3, "fkernel": GAUSS16},
-    {"type": OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": [1] * 9},
-    {"type": OP_SOBEL},
-]
+OP_DILATE, OP_ERODE, OP_OTSU, OP_FEATURES = 9, 10, 12, 15
+
+
+def p_a_ops(linear_kernel="binomial16"):
+    return [
+        {"type": OP_EQUALIZE},
+        {"type": OP_GAUSS, "mean": -1.0, "stddev": -1.0},
+        {"type": OP_SP, "iparam": 50},
+        {"type": OP_LINEAR, "kW": 3, "kH": 3, "fkernel": GAUSS16 if linear_kernel == "binomial16" else CONFIG_KERNEL},
+        {"type": OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": [1] * 9},
+        {"type": OP_SOBEL},
+    ]
+
+
+P_A = p_a_ops()
 # launch group -> the HIP kernel that does its image pass (names as rocprofv3 prints them)
 KERNEL_OF_GROUP = {
     "gray+hist": "iak::gray_kernel<0, true>",
@@ -50,19 +124,14 @@ KERNEL_OF_GROUP = {
     "median": "iak::stencil8_kernel<iak::Median8, 8, false, false>",
     "sobel": "iak::stencil8_kernel<iak::Sobel8, 8, false, false>",
 }
-# kernels behind the group names of the other two workloads, where they differ from P-A's
+# kernels behind the group names of the other workloads, where they differ from P-A's
 KERNEL_OF_GROUP_BY_WORKLOAD = {
+    "P-A/config": {"equalize+gauss+salt_pepper+linear": "iak::chain_stencil8_flat_kernel<iak::Lin8Pk16>",
+                   "linear": "iak::stencil8_kernel<iak::Lin8Pk16, 8, false, false>"},
     "P-B": {"linear": "iak::tiled_linear_kernel<11, false, true>", "median": "iak::huang_median_kernel<7>"},
     "P-C": {"otsu": "iak::chain_apply_kernel<false>", "otsu+sobel": "iak::binary_table_stencil_kernel",
             "dilate+erode+hist": "iak::morph_chain_kernel<2, 2, false>", "features": "iak::perimeter_bits_kernel"},
 }
-# The histogram rides on the grayscale pass (the pixel is still in a register), so that kernel's
-# compulsory traffic is the grayscale conversion's alone: 3 bytes read + 1 written per pixel.
-KERNEL_BYTES_PER_PX = {"gray+hist": 4}
-P_A_BYTES_PER_PX = 19
-# The other two pipelines of the measurement plan; parity-test cases first, available here with
-# --workload for the record (the default line is P-A).
-OP_DILATE, OP_ERODE, OP_OTSU, OP_FEATURES = 9, 10, 12, 15
 P_B = [
     {"type": OP_LINEAR, "kW": 11, "kH": 11, "fkernel": [1.0 / 121] * 121},
     {"type": OP_MEDIAN, "kW": 7, "kH": 7, "ikernel": [1] * 49},
@@ -71,13 +140,16 @@ P_C = [
     {"type": OP_OTSU}, {"type": OP_SOBEL}, {"type": OP_DILATE, "kW": 3, "kH": 3, "ikernel": [1] * 9},
     {"type": OP_ERODE, "kW": 3, "kH": 3, "ikernel": [0, 1, 0, 1, 1, 1, 0, 1, 0]}, {"type": OP_FEATURES},
 ]
-WORKLOADS = {  # name: (ops, W, H, default images per GPU, stage-wise bytes per pixel, description)
+# name: (ops, W, H, default images per GPU, stage-wise bytes per pixel of the reference's one-kernel-per-operation
+# flow, description).  Stage-wise: gray 4, hist 1, equalise 2, gaussian 3, salt-pepper 3, linear 2, median 2, sobel 2.
+WORKLOADS = {
     "P-A": (P_A, 768, 568, 500, 19, "full pipeline (gray, histogram, equalize, gaussian noise, salt-and-pepper 50, "
             "3x3 linear, 3x3 median, sobel)"),
     "P-B": (P_B, 4096, 4096, 8, 8, "large-stencil stress (gray, 11x11 linear box, 7x7 median)"),
     "P-C": (P_C, 768, 568, 500, 14, "segmentation path (gray, histogram, otsu, sobel, 3x3 dilation, 3x3 erosion, "
-            "7 features per image)"),
-}  # gray 4, hist 1, equalise 2, gaussian 3, salt-pepper 3, linear 2, median 2, sobel 2
+            "7 features per image, per-class feature statistics)"),
+}
+N_CLASSES = 6  # the data set's class count (imageMachineLearning.cu:212); synthetic label = image index % 6
 
 
 def make_cell_batch(B, device, seed):
@@ -88,7 +160,7 @@ def make_cell_batch(B, device, seed):
     out = torch.empty((B, 3, H, W), dtype=torch.uint8, device=device)
     yy = torch.arange(H, device=device, dtype=torch.float32).view(1, H, 1)
     xx = torch.arange(W, device=device, dtype=torch.float32).view(1, 1, W)
-    step = 50
+    step = max(1, min(50, (50 * 768 * 568) // (W * H)))
     for s in range(0, B, step):
         n = min(step, B - s)
         base = 200.0 + 8.0 * torch.randn((n, H, W), generator=g, device=device)
@@ -107,7 +179,7 @@ def make_cell_batch(B, device, seed):
     return out
 
 
-def cpu_baseline(rgb_dev, n_threads, ops):
+def cpu_baseline(rgb_dev, n_threads, ops, cpu_seconds=24.0):
     """The CPU oracle (a port of the reference's CUDA kernels, oracle/ia_oracle.c) on a
     bounded sample of the same batch, on this machine's host cores."""
     import oracle_lib as O
@@ -118,9 +190,9 @@ def cpu_baseline(rgb_dev, n_threads, ops):
     ops = [o for o in ops if o["type"] != OP_FEATURES]  # the image path; features are checked in the tests
     O.pipeline(probe, ops, x0, x1, threads=n_threads)
     dt = time.perf_counter() - t0
-    per_image_cpu_s = dt * n_threads / probe.shape[0]
-    # about 15 s of CPU work in total, at least one image per thread, at most what we hold
-    n = int(max(n_threads, min(rgb_dev.shape[0], 15.0 / max(per_image_cpu_s, 1e-6))))
+    per_image_cpu_s = dt * min(n_threads, probe.shape[0]) / probe.shape[0]
+    # about cpu_seconds of CPU work in total, at least one image per thread, at most what we hold
+    n = int(max(n_threads, min(rgb_dev.shape[0], cpu_seconds / max(per_image_cpu_s, 1e-6))))
     n = max(n_threads, (n // n_threads) * n_threads)
     n = min(n, rgb_dev.shape[0])
     sample = rgb_dev[:n].cpu().numpy()
@@ -133,191 +205,310 @@ def cpu_baseline(rgb_dev, n_threads, ops):
     O.pipeline(sample[:n1], ops, x0, x1, threads=1)
     dt1 = time.perf_counter() - t1
     return {
-        "value": round(n * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "cores": n_threads, "kind": "port",
+        "value": float(f"{n * W * H / dt / 1e6:.3g}"), "unit": "Mpixels/s", "cores": n_threads, "kind": "port",
         "sample": f"{n} of the batch's {W}x{H} images, same pipeline, OpenMP over images, {dt:.2f} s wall",
-        "value_1_core": round(n1 * W * H / dt1 / 1e6, 2), "host_cpus": os.cpu_count(),
+        "value_1_core": float(f"{n1 * W * H / dt1 / 1e6:.3g}"), "host_cpus": os.cpu_count(),
     }, out, n
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (default: the workload's)")
-    ap.add_argument("--workload", default="P-A", choices=sorted(WORKLOADS))
-    ap.add_argument("--stagewise", action="store_true", help="one pass per operation (no fusion)")
-    ap.add_argument("--pointwise", action="store_true", help="fuse per-pixel runs only; stencils stay separate passes")
-    ap.add_argument("--strips", action="store_true", help="also fuse runs of 3x3 stencils through LDS strips")
-    ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per GPU (executor streams)")
-    ap.add_argument("--settle-ms", type=float, default=100.0,
-                    help="run the pipeline untimed for this long before the warm-up steps (clock ramp after the idle "
-                         "gap of input generation); 0 disables")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise RCCL and run the all-reduce path even with one rank (self-test of the multi-GPU path)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel events in the timed steps (no roofline)")
-    args = ap.parse_args()
+def _load_profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
 
+
+def init_dist(args, world, local_rank, dev):
+    """RCCL (or gloo for the one-GPU rehearsal) up, first collective done.  RCCL writes its
+    version banner to stdout when the communicator comes up; stdout is reserved for the one JSON
+    line, so file descriptor 1 points at stderr until the first collective has run."""
+    import torch.distributed as dist
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        backend = "gloo" if args.rehearse_on_one_gpu else "nccl"
+        kw = {} if backend == "gloo" else {"device_id": dev}
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            dist.init_process_group(backend, rank=0, world_size=1, **kw)
+        else:
+            dist.init_process_group(backend, **kw)
+        probe = torch.zeros(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    return dist
+
+
+class Measurement:
+    """One workload on this rank's GPU: pipeline, buffers, the step function with its (optional)
+    asynchronous dataset reduction, and the timed loop."""
+
+    def __init__(self, args, name, ops, B, dev, rank, dist, mode):
+        global W, H
+        _, W, H, _, self.stagewise_bytes, self.what = WORKLOADS[name]
+        self.name, self.ops, self.B, self.dev, self.dist = name, ops, B, dev, dist
+        self.rgb = make_cell_batch(B, dev, seed=0x1A2B3C4D + rank)
+        self.out = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        self.pipe = Pipeline(W, H, B, ops, fused=mode)
+        self.pipe.set_lanes(args.lanes)
+        self.feats = None
+        if any(o["type"] == OP_FEATURES for o in ops):
+            from imageanalysis_amd.dist import PackedDatasetStats
+            self.feats = torch.zeros((B, 7), dtype=torch.float32, device=dev)
+            self.pipe.bind_features(self.feats)
+            self.labels = ((torch.arange(B, device=dev, dtype=torch.int64) + rank * B) % N_CLASSES).to(torch.int32)
+            # two packed buffers (histogram + per-class count / sum / sum of squares): ONE collective per step
+            self.packed = [PackedDatasetStats(N_CLASSES, dev) for _ in range(2)]
+        # Two histogram buffers: the all-reduce of one batch's sums runs on the collective's stream
+        # while the next batch is already being processed into the other buffer.
+        self.hist_bufs = [torch.zeros(256, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.pending = [None, None]
+        self.counter = 0
+
+    def step(self):
+        # the batch's grayscale histogram is added to the buffer by the run; across GPUs the
+        # dataset-level sums are the one exchange of the path (a few KiB, latency-bound)
+        k = self.counter & 1
+        self.counter += 1
+        if self.pending[k] is not None:
+            self.pending[k].wait()  # the reduction issued two steps ago: orders this stream after it, no host wait
+            self.pending[k] = None
+        self.hist_bufs[k].zero_()
+        self.pipe.run(self.rgb, out=self.out, hist_sum=self.hist_bufs[k])
+        if self.feats is not None:
+            self.packed[k].fill(self.hist_bufs[k], self.feats, self.labels)
+            if self.dist is not None:
+                self.pending[k] = self.packed[k].all_reduce_async()
+        elif self.dist is not None:
+            self.pending[k] = self.dist.all_reduce(self.hist_bufs[k], op=self.dist.ReduceOp.SUM, async_op=True)
+
+    def drain(self):
+        for k in range(2):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
+
+    def run(self, steps, warmup, settle_ms, events=True):
+        if settle_ms > 0:
+            # The GPU has been idle or running small torch kernels while the inputs were made; its clocks take
+            # some tens of milliseconds of load to come back up.  Untimed, like the warm-up steps.
+            t_end = time.perf_counter() + settle_ms * 1e-3
+            while time.perf_counter() < t_end:
+                for _ in range(10):
+                    self.step()
+                torch.cuda.synchronize()
+        for _ in range(warmup):
+            self.step()
+        # per-kernel HIP events on a sample of the timed steps (every 8th, at least one): each timed
+        # step pays about 20 us for its ten event records
+        every = 1 if steps < 16 else 8
+        nrec = 0 if not events else min((steps + every - 1) // every, 256)
+        self.pipe.set_timing(nrec, every=every)
+        self.drain()
+        dist = self.dist
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.drain()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        # per-launch-group durations from the HIP events recorded inside the timed steps
+        acc = None
+        for sl in range(nrec):
+            t = self.pipe.timings(sl)
+            if acc is None:
+                acc = [[n, 0.0, b, 0.0] for n, _, b, _ in t]
+            for i, (_, ms, _, main_ms) in enumerate(t):
+                acc[i][1] += ms
+                acc[i][3] += main_ms
+        self.groups = [(n, ms / max(nrec, 1), b, mm / max(nrec, 1)) for n, ms, b, mm in acc] if acc else []
+        self.pipe.set_timing(0)
+        return dt
+
+    def report(self, dt, steps, world, variant=None):
+        """Throughput, per-group figures and the dominant kernel's roofline, on the bytes the
+        executed plan moves (image read + image written per launch group)."""
+        B = self.B
+        timed_images = self.pipe.timed_images()
+        moved = self.pipe.moved_bytes()
+        px = B * W * H
+        value = px * world * steps / dt / 1e6
+        kernel_of = dict(KERNEL_OF_GROUP, **KERNEL_OF_GROUP_BY_WORKLOAD.get(variant or self.name, {}))
+        traffic = _load_profile_json("traffic.json")
+        valu = _load_profile_json("valu.json")
+        tpx = timed_images * W * H
+        groups = []
+        for (n, ms, stage_b, mm), mv in zip(self.groups, moved):
+            g = {"name": n, "kernel": kernel_of.get(n, n), "ms": round(ms, 4), "kernel_ms": round(mm, 4), "images": timed_images,
+                 "moved_bytes_per_px": mv, "stagewise_bytes_per_px": stage_b}
+            if mm > 0:
+                gbps = mv * tpx / (mm * 1e-3) / 1e9
+                g["moved_GBps"] = round(gbps, 1)
+                g["hbm_frac"] = round(gbps / HBM_PEAK_GBS, 4)
+                g["bound"] = "hbm"
+                v = valu.get(kernel_of.get(n, n))
+                if v and v.get("batch") == B:
+                    # share of the launch during which the vector pipes were issuing, from the SQ counter pass
+                    issue_s = v["valu_busy_cycles_per_launch"] / N_SIMDS / CLOCK_HZ
+                    g["valu_issue_frac"] = round(issue_s / (mm * 1e-3), 4)
+                    if g["valu_issue_frac"] > g["hbm_frac"]:
+                        g["bound"] = "valu"
+                tr = traffic.get(n)
+                if tr and tr.get("batch") == B and tr.get("kernel") == g["kernel"]:
+                    g["traffic_bytes_per_launch"] = tr["hbm_bytes_per_launch"]
+            groups.append(g)
+        moved_total = sum(moved)
+        line = {
+            "value": round(value, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+            "pipeline_moved_bytes_per_px": moved_total,
+            # fraction of HBM peak on the bytes the executed plan has to move (<= 1 by construction)
+            "pipeline_hbm_frac_moved_bytes": round(value * 1e6 / world * moved_total / (HBM_PEAK_GBS * 1e9), 4),
+            "pipeline_stagewise_bytes_per_px": self.stagewise_bytes,
+            "groups": groups,
+        }
+        if groups and all("traffic_bytes_per_launch" in g for g in groups):
+            tb = sum(g["traffic_bytes_per_launch"] for g in groups)
+            # the same with the HBM bytes the counters saw (profiles/traffic.json)
+            line["pipeline_hbm_frac_counter_traffic"] = round(tb / (dt / steps) / (HBM_PEAK_GBS * 1e9), 4)
+        dom = max(groups, key=lambda g: g["kernel_ms"]) if groups else None
+        if dom and dom["kernel_ms"] > 0:
+            alg = dom["moved_bytes_per_px"]
+            achieved = alg * tpx / (dom["kernel_ms"] * 1e-3) / 1e9
+            line["roofline"] = {"bound": dom.get("bound", "hbm"), "kernel": dom["kernel"], "group": dom["name"],
+                                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": dom.get("traffic_bytes_per_launch"),
+                                "algorithmic_bytes_per_px": alg, "avg_ms": dom["kernel_ms"], "bytes_per_launch": alg * tpx}
+            if "valu_issue_frac" in dom:
+                line["roofline"]["valu_issue_frac"] = dom["valu_issue_frac"]
+        return line
+
+    def close(self):
+        self.pipe.close()
+        self.rgb = self.out = self.feats = None
+        torch.cuda.empty_cache()
+
+
+def _mode_of(args):
+    return False if args.stagewise else ("pointwise" if args.pointwise else ("strips" if args.strips else True))
+
+
+def _threads(B):
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    return max(1, min(threads, os.cpu_count() or 1, B))
+
+
+def side_measurement(args, name, ops, B, dev, variant, steps, cpu_seconds):
+    """A short run of another workload for the record: ms per step, dominant kernel and its
+    fraction, and a full-size comparison of a sample with the CPU oracle."""
+    m = Measurement(args, name, ops, B, dev, 0, None, True)
+    dt = m.run(steps, 3, 50.0)
+    rep = m.report(dt, steps, 1, variant=variant)
+    res = {"workload": f"{B} x {W}x{H}: {m.what}", "ms_per_step": rep["ms_per_step"], "value": rep["value"],
+           "unit": "Mpixels/s", "steps": steps, "moved_bytes_per_px": rep["pipeline_moved_bytes_per_px"],
+           "hbm_frac_moved_bytes": rep["pipeline_hbm_frac_moved_bytes"],
+           "groups": [{k: g[k] for k in ("name", "kernel_ms", "moved_bytes_per_px", "hbm_frac", "bound", "valu_issue_frac")
+                       if k in g} for g in rep["groups"]]}
+    if "roofline" in rep:
+        r = rep["roofline"]
+        res["dominant"] = {"kernel": r["kernel"], "avg_ms": r["avg_ms"], "frac": r["frac"], "bound": r["bound"]}
+    if not args.no_cpu_baseline:
+        base, ref_out, n = cpu_baseline(m.rgb, _threads(B), ops, cpu_seconds=cpu_seconds)
+        res["cpu_Mpixels_per_s"] = base["value"]
+        res["cpu_cores"] = base["cores"]
+        res["cpu_sample_images"] = n
+        res["matches_cpu"] = bool(np.array_equal(m.out[:n].cpu().numpy(), ref_out))
+    m.close()
+    return res
+
+
+def main():
+    args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the HIP path")
+    n_dev = torch.cuda.device_count()
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
+    elif local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but this machine has {n_dev} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist
-        # RCCL writes its version banner (NCCL_DEBUG=VERSION) to stdout when the communicator comes
-        # up; stdout is reserved for the one JSON line, so file descriptor 1 points at stderr until
-        # the first collective has run.
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            if world == 1:
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29517")
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-            else:
-                dist.init_process_group("nccl", device_id=dev)
-            probe = torch.zeros(1, dtype=torch.int64, device=dev)
-            dist.all_reduce(probe)
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
+    dist = init_dist(args, world, local_rank, dev) if (world > 1 or args.force_dist) else None
     iak_lib.load()
 
-    global W, H
-    ops, W, H, default_B, bytes_per_px, what = WORKLOADS[args.workload]
-    B = args.batch or default_B
-    rgb = make_cell_batch(B, dev, seed=0x1A2B3C4D + rank)
-    out = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-    pipe = Pipeline(W, H, B, ops, fused=False if args.stagewise else ("pointwise" if args.pointwise else ("strips" if args.strips else True)))
-    pipe.set_lanes(args.lanes)
-    if any(o["type"] == OP_FEATURES for o in ops):
-        feats = torch.zeros((B, 7), dtype=torch.float32, device=dev)
-        pipe.bind_features(feats)
-    # Two histogram buffers: the all-reduce of one batch's histogram runs on RCCL's stream while the
-    # next batch is already being processed into the other buffer.
-    hist_bufs = [torch.zeros(256, dtype=torch.int64, device=dev) for _ in range(2)]
-    pending = [None, None]
-    counter = [0]
-
-    def step():
-        # the batch's grayscale histogram is added to the buffer by the run; across GPUs the
-        # dataset-level histogram is the one exchange of the path (2 KiB, latency-bound)
-        k = counter[0] & 1
-        counter[0] += 1
-        if pending[k] is not None:
-            pending[k].wait()  # the reduction issued two steps ago: orders this stream after it, no host wait
-            pending[k] = None
-        hist_bufs[k].zero_()
-        pipe.run(rgb, out=out, hist_sum=hist_bufs[k])
-        if dist is not None:
-            pending[k] = dist.all_reduce(hist_bufs[k], op=dist.ReduceOp.SUM, async_op=True)
-
-    def drain():
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
-
-    if args.settle_ms > 0:
-        # The GPU has been idle or running small torch kernels while the inputs were made; its clocks take
-        # some tens of milliseconds of load to come back up.  Untimed, like the warm-up steps.
-        t_end = time.perf_counter() + args.settle_ms * 1e-3
-        while time.perf_counter() < t_end:
-            for _ in range(10):
-                step()
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    # per-kernel HIP events on a sample of the timed steps (every 8th, at least one): each timed
-    # step pays about 20 us for its ten event records
-    every = 1 if args.steps < 16 else 8
-    nrec = 0 if args.no_events else min((args.steps + every - 1) // every, 256)
-    pipe.set_timing(nrec, every=every)
-    drain()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # per-launch-group durations from the HIP events recorded inside the timed steps
-    acc = None
-    for sl in range(nrec):
-        t = pipe.timings(sl)
-        if acc is None:
-            acc = [[n, 0.0, b, 0.0] for n, _, b, _ in t]
-        for i, (_, ms, _, main_ms) in enumerate(t):
-            acc[i][1] += ms
-            acc[i][3] += main_ms
-    groups = [(n, ms / max(nrec, 1), b, mm / max(nrec, 1)) for n, ms, b, mm in acc] if acc else []
-    timed_images = pipe.timed_images()  # images in the sub-batch that carried the events
+    ops = p_a_ops(args.linear_kernel) if args.workload == "P-A" else WORKLOADS[args.workload][0]
+    B = args.batch or WORKLOADS[args.workload][3]
+    variant = "P-A/config" if (args.workload == "P-A" and args.linear_kernel == "config") else None
+    m = Measurement(args, args.workload, ops, B, dev, rank, dist, _mode_of(args))
+    dt = m.run(args.steps, args.warmup, args.settle_ms, events=not args.no_events)
 
     if rank == 0:
-        px_per_step = B * W * H * world
-        value = px_per_step * args.steps / dt / 1e6
-        # dominant kernel: the image kernel of the slowest group, timed alone (HIP events on the
-        # executor's stream around that one launch)
-        dom = max(groups, key=lambda g: g[3]) if groups else None
-        roofline = None
-        if dom:
-            alg = KERNEL_BYTES_PER_PX.get(dom[0], dom[2])
-            achieved = alg * timed_images * W * H / (dom[3] * 1e-3) / 1e9
-            kernel_of = dict(KERNEL_OF_GROUP, **KERNEL_OF_GROUP_BY_WORKLOAD.get(args.workload, {}))
-            roofline = {"bound": "hbm", "kernel": kernel_of.get(dom[0], dom[0]), "group": dom[0],
-                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                        "algorithmic_bytes_per_px": alg, "avg_ms": round(dom[3], 4),
-                        "bytes_per_launch": alg * timed_images * W * H}
-            tr = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tr):
-                try:
-                    rec = json.load(open(tr)).get(dom[0])
-                    if rec and rec.get("batch") == B:
-                        roofline["traffic"] = rec["hbm_bytes_per_launch"]
-                except Exception:
-                    pass
+        rep = m.report(dt, args.steps, world, variant=variant)
+        lin = ("3x3 linear = binomial [1,2,1;2,4,2;1,2,1]/16 (kernel Lin8Swar)" if args.linear_kernel == "binomial16" else
+               "3x3 linear = [1,1,1,10,1,1,1,1,1] of test/configs/input.json (kernel Lin8Pk16)")
+        what = m.what + ("; " + lin if args.workload == "P-A" else "")
+        reduction = "dataset histogram" + (" + per-class feature statistics" if m.feats is not None else "")
         line = {
-            "metric": "Mpixels/sec (whole node) full filter pipeline", "value": round(value, 1), "unit": "Mpixels/s",
+            "metric": "Mpixels/sec (whole node) full filter pipeline", "value": rep["value"], "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"batch of {B} {W}x{H} RGB cell-like images per GPU, {what}, device-resident",
-                       "images_per_gpu": B, "settle_ms": args.settle_ms, "mode": "stagewise" if args.stagewise else ("fused-pointwise" if args.pointwise else ("fused-strips" if args.strips else "fused")), "lanes": args.lanes,
-                       "parallelism": f"image-wise shards x{world}, dataset-histogram all-reduce per step"},
-            "pipeline_frac_of_hbm_roofline": round(value * 1e6 * bytes_per_px / world / (HBM_PEAK_GBS * 1e9), 4),
-            "groups": [{"name": n, "ms": round(ms, 4), "kernel_ms": round(mm, 4), "images": timed_images,
-                        "alg_GBps": round(KERNEL_BYTES_PER_PX.get(n, b) * timed_images * W * H / (mm * 1e-3) / 1e9, 1)
-                        if mm > 0 else None}
-                       for n, ms, b, mm in groups],
-            "roofline": roofline,
+                       "images_per_gpu": B, "settle_ms": args.settle_ms,
+                       "mode": "stagewise" if args.stagewise else ("fused-pointwise" if args.pointwise else ("fused-strips" if args.strips else "fused")),
+                       "lanes": args.lanes,
+                       "parallelism": f"image-wise shards x{world}, one all-reduce of the {reduction} per step"},
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline belongs to the 1-GPU line only
-            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-            threads = max(1, min(threads, os.cpu_count() or 1, B))
-            base, ref_out, n = cpu_baseline(rgb, threads, ops)
+        # what the last step's reduction left: the dataset-level sums over all ranks
+        k_last = (m.counter - 1) & 1
+        if m.feats is not None:
+            count, mean, _ = m.packed[k_last].class_stats()
+            line["dataset"] = {"histogram_pixels": int(m.packed[k_last].histogram().sum().item()),
+                               "class_counts": [int(c) for c in count.tolist()],
+                               "class_mean_area": [round(float(a), 3) for a in mean[:, 2].tolist()]}
+        else:
+            line["dataset"] = {"histogram_pixels": int(m.hist_bufs[k_last].sum().item())}
+        if args.rehearse_on_one_gpu:
+            line["rehearsal"] = "all ranks on GPU 0, gloo reduction: exercises the multi-rank code path; not a measurement"
+        for k in ("pipeline_moved_bytes_per_px", "pipeline_hbm_frac_moved_bytes", "pipeline_hbm_frac_counter_traffic",
+                  "pipeline_stagewise_bytes_per_px", "groups", "roofline"):
+            if k in rep:
+                line[k] = rep[k]
+        solo = world == 1 and not args.force_dist
+        if not args.no_cpu_baseline and solo:  # the CPU baseline belongs to the 1-GPU line only
+            base, ref_out, n = cpu_baseline(m.rgb, _threads(B), ops)
             # the sample doubles as a full-size parity check of the timed path
-            base["matches_gpu"] = bool(np.array_equal(out[:n].cpu().numpy(), ref_out))
+            base["matches_gpu"] = bool(np.array_equal(m.out[:n].cpu().numpy(), ref_out))
             line["cpu_baseline"] = base
+        if solo and args.workload == "P-A" and not variant and not args.no_other_workloads and _mode_of(args) is True \
+                and not args.batch:
+            m.close()
+            other = {}
+            other["P-A with the configuration's linear kernel"] = side_measurement(
+                args, "P-A", p_a_ops("config"), WORKLOADS["P-A"][3], dev, "P-A/config", 30, 6.0)
+            other["P-B"] = side_measurement(args, "P-B", P_B, WORKLOADS["P-B"][3], dev, None, 10, 3.0)
+            other["P-C"] = side_measurement(args, "P-C", P_C, WORKLOADS["P-C"][3], dev, None, 30, 6.0)
+            line["other_workloads"] = other
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -150,6 +150,40 @@ __global__ __launch_bounds__(256) void perimeter_bits_kernel(const uint8_t *__re
     if ((threadIdx.x & 63) == 0 && n255) atomicAdd(&counts[b], n255);
 }
 
+// ---- dataset-level sums of one batch, packed for one collective -------------------------------
+// packed = [256 histogram bins | C counts | C x 7 feature sums | C x 7 sums of squares], doubles.
+// The reference's driver keeps the per-image feature rows and labels on the host
+// (test/test.cu:541-550) and a dataset histogram (:407-411); a multi-GPU job reduces these sums
+// instead.  One lane per output slot walks the images in order, so the sums do not depend on
+// scheduling; the integers stay exact in a double (far below 2^53).
+__global__ __launch_bounds__(256) void dataset_sums_kernel(const unsigned long long *__restrict__ hist_sum,
+                                                           const float *__restrict__ features,
+                                                           const int32_t *__restrict__ labels, int B, int C,
+                                                           double *__restrict__ packed) {
+    const int slots = 256 + C * (1 + 2 * FEAT_N);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += gridDim.x * blockDim.x) {
+        if (i < 256) {
+            packed[i] = hist_sum ? (double)hist_sum[i] : 0.0;
+            continue;
+        }
+        const int j = i - 256;
+        double acc = 0.0;
+        if (j < C) {
+            for (int b = 0; b < B; b++) acc += labels[b] == j ? 1.0 : 0.0;
+        } else {
+            const int k = j - C;
+            const bool sq = k >= C * FEAT_N;
+            const int c = (sq ? k - C * FEAT_N : k) / FEAT_N, f = (sq ? k - C * FEAT_N : k) % FEAT_N;
+            for (int b = 0; b < B; b++)
+                if (labels[b] == c) {
+                    const double v = (double)features[(long long)b * FEAT_N + f];
+                    acc += sq ? v * v : v;
+                }
+        }
+        packed[i] = acc;
+    }
+}
+
 // ---- kMeansThresholding (imageAnalysis.cu:281-379), k = 2, on the histogram ------------------
 // One wave per image, four bins per lane.  Labels: 0 = nearer to centroid 1 (the reference's
 // inverted test, :298-302); class sums accumulate as unsigned int (wrapping like the
@@ -436,6 +470,16 @@ int iak_features_static(const uint8_t *img, int W, int H, int B, long long strid
     const int rc = features_static_scratch(&sc);
     if (rc) return rc;
     return features_one_pass(img, W, H, B, stride, hist, features, sc->hist, sc->counts, sc->thr, stream);
+}
+
+int iak_dataset_sums(const unsigned long long *hist_sum, const float *features, const int32_t *labels, int B, int C,
+                     double *packed, void *stream) {
+    if (!packed || B < 0 || C < 0 || C > 4096 || (B > 0 && C > 0 && (!features || !labels))) return IAK_E_ARG;
+    const int slots = 256 + C * (1 + 2 * FEAT_N);
+    hipLaunchKernelGGL(dataset_sums_kernel, dim3((slots + 255) / 256), dim3(256), 0, as_stream(stream), hist_sum, features,
+                       labels, B, C, packed);
+    IAK_LAUNCH_CHECK();
+    return 0;
 }
 
 int iak_kmeans2_map(const uint32_t *hist, int numPixels, int B, const int32_t *init_centroids, int32_t *map,

@@ -1057,6 +1057,30 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
     return 0;
 }
 
+// Bytes per pixel a group has to move as it is executed: what its passes read from and write to
+// image-sized arrays.  Intermediates a fused group keeps on chip do not count, nor do the noise
+// planes (one image's worth, shared by the whole batch).
+static long long group_moved_bytes(const iak_pipeline *p, const Group &g) {
+    switch (g.kind) {
+    case G_GRAYHIST: return p->input <= IAK_INPUT_AVERAGE ? 4 : 2;
+    case G_HIST: case G_FEATURES: return 1;
+    case G_CHAIN: case G_CHAIN_OP: case G_STRIP: case G_MORPH: return 2;
+    case G_OP: {
+        const iak_op &o = p->ops[g.op_index].op;
+        return 2 + ((needs_hist(o) && !g.emit_hist) ? 1 : 0);  // stage-wise: a counting pass of its own first
+    }
+    }
+    return 0;
+}
+
+int iak_pipeline_group_bytes(iak_pipeline *p, long long *moved_bytes_per_px, int cap) {
+    if (!p) return IAK_E_ARG;
+    const int n = (int)p->groups.size();
+    for (int i = 0; i < n && i < cap; i++)
+        if (moved_bytes_per_px) moved_bytes_per_px[i] = group_moved_bytes(p, p->groups[i]);
+    return n;
+}
+
 int iak_pipeline_set_lanes(iak_pipeline *p, int lanes) {
     if (!p || lanes < 1 || lanes > 8) return IAK_E_ARG;
     while ((int)p->aux.size() < lanes - 1) {

@@ -62,3 +62,58 @@ def allreduce_class_stats(buffers):
     mean = s / n
     var = (ss / n - mean * mean).clamp(min=0)
     return count, mean, var.sqrt()
+
+
+class PackedDatasetStats:
+    """The dataset-level sums of one batch in ONE buffer, so that one collective carries them
+    all: [ 256 histogram bins | C counts | C x 7 feature sums | C x 7 sums of squares ] as
+    float64.  Every integer in it stays far below 2^53 (10,000 images of 768x568 are 4.4e9
+    pixels), so the integer parts are summed exactly whatever the number of ranks."""
+
+    def __init__(self, n_classes, device):
+        self.C = int(n_classes)
+        self.buf = torch.zeros(256 + self.C * (1 + 2 * N_FEATURES), dtype=torch.float64, device=device)
+        c, f = self.C, N_FEATURES
+        self.hist = self.buf[:256]
+        self.count = self.buf[256:256 + c]
+        self.sum = self.buf[256 + c:256 + c + c * f].view(c, f)
+        self.sumsq = self.buf[256 + c + c * f:].view(c, f)
+
+    def fill(self, hist_int64, features, labels):
+        """This batch: the histogram the executor accumulated (int64[256]), the feature rows
+        (float32 [n,7], as IAK_OP_FEATURES wrote them) and their class labels (int64 [n])."""
+        if self.buf.is_cuda:
+            # one kernel of the library (iak_dataset_sums), on the current stream
+            from . import lib as _l
+            lab = labels if labels.dtype == torch.int32 else labels.to(torch.int32)
+            assert features.dtype == torch.float32 and features.is_contiguous() and lab.is_contiguous()
+            assert hist_int64.dtype == torch.int64 and hist_int64.is_contiguous()
+            _l.check(_l.load().iak_dataset_sums(hist_int64.data_ptr(), features.data_ptr(), lab.data_ptr(),
+                                                int(features.shape[0]), self.C, self.buf.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream), "iak_dataset_sums")
+            return
+        self.buf.zero_()
+        self.hist.copy_(hist_int64)
+        f = features.to(torch.float64)
+        self.count.index_add_(0, labels, torch.ones(labels.shape, dtype=torch.float64, device=labels.device))
+        self.sum.index_add_(0, labels, f)
+        self.sumsq.index_add_(0, labels, f * f)
+
+    def all_reduce_async(self):
+        return dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, async_op=True)
+
+    def all_reduce(self):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)
+        return self
+
+    def histogram(self):
+        """int64[256], exact."""
+        return self.hist.round().to(torch.int64)
+
+    def class_stats(self):
+        """(count int64[C], mean float64[C,7], std float64[C,7]) of the reduced sums."""
+        n = self.count.clamp(min=1).unsqueeze(1)
+        mean = self.sum / n
+        var = (self.sumsq / n - mean * mean).clamp(min=0)
+        return self.count.round().to(torch.int64), mean, var.sqrt()

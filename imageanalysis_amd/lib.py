@@ -66,6 +66,7 @@ SIGNATURES = {
     "iak_features": [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp],
     "iak_features_static_max_images": [],
     "iak_features_static": [_vp, _i, _i, _i, _ll, _vp, _vp, _vp],
+    "iak_dataset_sums": [_vp, _vp, _vp, _i, _i, _vp, _vp],
     "iak_kmeans2_map": [_vp, _i, _i, _vp, _vp, _vp, _vp],
     "iak_glibc_rand_seed": [_vp, C.c_uint, _vp],
     "iak_glibc_rand_centroids": [_vp, _i, _i, _vp, _vp],
@@ -80,6 +81,7 @@ SIGNATURES = {
     "iak_pipeline_set_timing": [_vp, _i],
     "iak_pipeline_set_timing_every": [_vp, _i],
     "iak_pipeline_timings": [_vp, _i, _vp, _vp, _vp, _vp, _i],
+    "iak_pipeline_group_bytes": [_vp, _vp, _i],
 }
 _RESTYPE = {"iak_error_string": C.c_char_p, "iak_features_workspace_bytes": C.c_longlong}
 

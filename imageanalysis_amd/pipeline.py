@@ -152,6 +152,16 @@ class Pipeline:
             raise _l.IakError(n, "iak_pipeline_timings")
         return [(names[i].decode(), int(ab[i])) for i in range(n)]
 
+    def moved_bytes(self):
+        """Bytes per pixel each launch group moves through memory as executed (see
+        iak_pipeline_group_bytes)."""
+        cap = 64
+        mb = (C.c_longlong * cap)()
+        n = _l.load().iak_pipeline_group_bytes(self._h, mb, cap)
+        if n < 0:
+            raise _l.IakError(n, "iak_pipeline_group_bytes")
+        return [int(mb[i]) for i in range(n)]
+
     def timings(self, slot=0):
         """[(name, ms, algorithmic bytes per pixel, ms of the group's image kernel alone)] of the
         timed run in `slot` (synchronises)."""

@@ -198,6 +198,16 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
 int iak_features_static_max_images(void);
 int iak_features_static(const uint8_t *img, int W, int H, int B, long long stride, const uint32_t *hist,
                         float *features, void *stream);
+/* The dataset-level sums of one batch, packed into one array so that ONE collective (or one host
+ * merge) carries them: packed[0..256) = hist_sum (the dataset histogram iak_pipeline_run
+ * accumulates, test/test.cu:407-411; zeros if NULL), then C per-class image counts, C x 7
+ * per-class feature sums, C x 7 sums of squares, as doubles (DEVICE double[256 + 15 * C], fully
+ * overwritten).  features: DEVICE float[B][7] as iak_features / IAK_OP_FEATURES write them;
+ * labels: DEVICE int32[B], class of image b in [0, C) (test/test.cu:541-550 keeps the same rows
+ * and labels on the host); other labels are not counted.  Sums run over the images in order:
+ * results do not depend on scheduling, and every integer stays exact (< 2^53). */
+int iak_dataset_sums(const unsigned long long *hist_sum, const float *features, const int32_t *labels, int B,
+                     int C, double *packed, void *stream);
 /* kMeansThresholding (imageAnalysis.cu:281-379; k = 2) on histograms: map[b][v] = 0 or 255, the
  * value applyLabels (:339-349) gives a pixel of value v; apply it with iak_apply_map.
  * init_centroids: DEVICE int32[B][2], the two random(0,256) draws of each image (:359-361).
@@ -315,6 +325,13 @@ int iak_pipeline_set_timing(iak_pipeline *p, int slots);
 int iak_pipeline_set_timing_every(iak_pipeline *p, int every);
 int iak_pipeline_timings(iak_pipeline *p, int slot, float *ms, float *main_ms, const char **names,
                          long long *alg_bytes_per_px, int cap);
+
+/* Bytes per pixel each launch group moves between HBM-sized arrays as the plan executes it
+ * (image read + image written; intermediates a fused group keeps on chip and the batch-shared
+ * noise planes do not count) -- the denominator of a roofline fraction for the executed plan,
+ * as opposed to alg_bytes_per_px above, which adds up the stage-wise traffic of the reference's
+ * one-kernel-per-operation flow (test/test.cu:326-564).  Returns the number of groups. */
+int iak_pipeline_group_bytes(iak_pipeline *p, long long *moved_bytes_per_px, int cap);
 
 #ifdef __cplusplus
 }

@@ -10,8 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from imageanalysis_amd.dist import (accumulate_class_stats, allreduce_class_stats, allreduce_histogram,
-                                    class_stat_buffers, shard_range)
+from imageanalysis_amd.dist import (PackedDatasetStats, accumulate_class_stats, allreduce_class_stats,
+                                    allreduce_histogram, class_stat_buffers, shard_range)
 
 W, H, B, C = 48, 20, 7, 3
 
@@ -63,6 +63,14 @@ def _worker(rank, world, port, out_q):
     if hi > lo:
         accumulate_class_stats(buf, torch.from_numpy(feats[lo:hi]), torch.from_numpy(labels[lo:hi]))
     count, mean, std = allreduce_class_stats(buf)
+    # the same sums through the packed buffer: histogram and class statistics in ONE collective
+    packed = PackedDatasetStats(C, "cpu")
+    packed.fill(torch.from_numpy(hists[lo:hi].sum(axis=0)) if hi > lo else torch.zeros(256, dtype=torch.int64),
+                torch.from_numpy(feats[lo:hi]), torch.from_numpy(labels[lo:hi]))
+    packed.all_reduce_async().wait()
+    pc, pm, ps = packed.class_stats()
+    assert torch.equal(packed.histogram(), h) and torch.equal(pc, count)
+    assert torch.allclose(pm, mean, rtol=1e-13, atol=0) and torch.allclose(ps, std, rtol=1e-9, atol=1e-9)
     if rank == 0:
         out_q.put((h.numpy(), count.numpy(), mean.numpy(), std.numpy()))
     dist.barrier()
