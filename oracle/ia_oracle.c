@@ -1,6 +1,7 @@
 /*
  * ia_oracle.c -- CPU restatement of imageAnalysisLib's per-pixel path.
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see ia_oracle.h).
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED except for the reference's host-only
+ * functions (see ia_oracle.h).
  *
  * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).
  * Every loop below is "one logical thread per pixel, tid in [0,N)": the
@@ -126,6 +127,8 @@ static int otsu_from_hist(const int *hist, long long sum_ll, int totalPixels) {
     return threshold;
 }
 
+int iao_otsu_from_hist(const int *hist, long long sum, int numPixels) { return otsu_from_hist(hist, sum, numPixels); }
+
 int iao_otsu(const uint8_t *in, uint8_t *out, int W, int H) {
     long N = (long)W * H;
     int hist[256];
@@ -140,6 +143,10 @@ int iao_otsu(const uint8_t *in, uint8_t *out, int W, int H) {
 void iao_mean_std_from_hist(const long long *cnt, long N, float *mean, float *stddev) {
     long long sum = 0;
     for (int v = 0; v < 256; v++) sum += cnt[v] * v;
+    iao_mean_std_from_hist_sum(cnt, N, sum, mean, stddev);
+}
+
+void iao_mean_std_from_hist_sum(const long long *cnt, long N, long long sum, float *mean, float *stddev) {
     float m = (float)sum / (float)N; /* :116 */
     double acc = 0.0;
     for (int v = 0; v < 256; v++) {
@@ -567,6 +574,29 @@ void iao_erode(const uint8_t *in, uint8_t *out, int W, int H, const int *se, int
 
 /* ------------------------------------------------- segmentation / features */
 
+int iao_centroids_changed(uint8_t *cent, int k) {
+    /* centroidsHaveChanged, imageAnalysis.cu:281-293: cent = k current values, then k new ones */
+    int changed = 0;
+    for (int i = 0; i < k; i++)
+        if ((cent[i] ^ cent[i + k]) != 0) {
+            cent[i] = cent[i + k];
+            changed = 1;
+        }
+    return changed;
+}
+
+int iao_random_from_rand(int lo, int hi, int rand_value) {
+    /* random(), imageAnalysis.cu:39-41, on one value of libc rand() (RAND_MAX = 2^31 - 1) */
+    return lo + rand_value / (2147483647 / (hi - lo + 1) + 1);
+}
+
+int iao_array_sum(const int *a, int n) {
+    /* arraySum, imageAnalysis.cu:682-688 */
+    int sum = 0;
+    for (int i = 0; i < n; i++) sum += a[i];
+    return sum;
+}
+
 int iao_kmeans2(const uint8_t *in, uint8_t *out, long N, int c0, int c1) {
     uint8_t cent[4] = {(uint8_t)c0, (uint8_t)c1, 0, 0};
     uint8_t *labels = (uint8_t *)malloc((size_t)N);
@@ -582,16 +612,36 @@ int iao_kmeans2(const uint8_t *in, uint8_t *out, long N, int c0, int c1) {
         for (int i = 0; i < 2; i++) /* :332 */
             cent[i + 2] = f2u8(floorf(sums[i] / (float)counts[i]));
         count++;
-        changed = 0;
-        for (int i = 0; i < 2; i++) /* :283-291 */
-            if ((cent[i] ^ cent[i + 2]) != 0) {
-                cent[i] = cent[i + 2];
-                changed = 1;
-            }
+        changed = iao_centroids_changed(cent, 2); /* :283-291 */
     } while (changed && count < 100);
     for (long t = 0; t < N; t++) out[t] = labels[t] == 0 ? 0 : 255; /* :342-347 */
     free(labels);
     return count;
+}
+
+int iao_hist_mode(const int *hist) {
+    /* calcMode, imageMachineLearning.cu:341-351 */
+    int maxVal = 0, mode = -1;
+    for (int i = 0; i < 256; i++)
+        if (maxVal < hist[i]) {
+            maxVal = hist[i];
+            mode = i;
+        }
+    return mode;
+}
+int iao_hist_area(const int *hist, int numPixels) {
+    /* calculateCellArea, imageMachineLearning.cu:353-360 */
+    return hist[255] < numPixels - hist[255] ? hist[255] : numPixels - hist[255];
+}
+int iao_hist_perimeter(const int *hist) { return hist[255]; /* calculateCellPerimeter, :362-366 */ }
+void iao_hist_range(const int *hist, int *rmin, int *rmax) {
+    /* calcMinAndMaxOfRange, imageMachineLearning.cu:379-391, from -1 / -1 (:406-407) */
+    *rmin = -1;
+    *rmax = -1;
+    for (int i = 0; i < 256; i++)
+        if (hist[i] != 0 && *rmin == -1) *rmin = i;
+    for (int i = 255; i >= 0; i--)
+        if (hist[i] != 0 && *rmin != -1 && *rmax == -1) *rmax = i;
 }
 
 void iao_features(const uint8_t *in, int W, int H, float *feat) {
@@ -604,22 +654,14 @@ void iao_features(const uint8_t *in, int W, int H, float *feat) {
     uint8_t *t2 = (uint8_t *)malloc((size_t)N);
     iao_otsu(in, t1, W, H);
     iao_hist(t1, N, hist);
-    int area = hist[255] < (int)N - hist[255] ? hist[255] : (int)N - hist[255]; /* :358 */
+    int area = iao_hist_area(hist, (int)N); /* :399-400 */
     iao_compass(t1, t2, W, H);
     iao_hist(t2, N, hist);
-    int perimeter = hist[255]; /* :364 */
+    int perimeter = iao_hist_perimeter(hist); /* :401-403 */
     iao_hist(in, N, hist);
-    int maxVal = 0, mode = -1; /* :341-351 */
-    for (int i = 0; i < 256; i++)
-        if (maxVal < hist[i]) {
-            maxVal = hist[i];
-            mode = i;
-        }
-    int rmin = -1, rmax = -1; /* :379-390 */
-    for (int i = 0; i < 256; i++)
-        if (hist[i] != 0 && rmin == -1) rmin = i;
-    for (int i = 255; i >= 0; i--)
-        if (hist[i] != 0 && rmin != -1 && rmax == -1) rmax = i;
+    int mode = iao_hist_mode(hist); /* :405 */
+    int rmin, rmax;
+    iao_hist_range(hist, &rmin, &rmax); /* :406-408 */
     feat[0] = mean;
     feat[1] = sd;
     feat[2] = (float)area;
@@ -775,6 +817,33 @@ void iao_knn_predict(const float *train, const float *test, int numTrain, int nu
 }
 
 #define IAO_NUM_CLASSES 6
+void iao_confusion_metrics(const int *pred, const float *rows, int A, int n, int *confusion, float *accuracy,
+                           float *precision, float *recall) {
+    /* computeConfusionMatrix / computeAccuracy / computePrecisionAndRecall,
+     * imageMachineLearning.cu:214-255.  confusion: IAO_NUM_CLASSES^2 ints, overwritten. */
+    memset(confusion, 0, sizeof(int) * IAO_NUM_CLASSES * IAO_NUM_CLASSES);
+    for (int i = 0; i < n; i++) { /* :214-227 */
+        int tc = (int)rows[(long)i * A + A - 1], pc = pred[i];
+        if (tc >= 0 && tc < IAO_NUM_CLASSES && pc >= 0 && pc < IAO_NUM_CLASSES) confusion[tc * IAO_NUM_CLASSES + pc]++;
+    }
+    int ok = 0;
+    for (int i = 0; i < IAO_NUM_CLASSES; i++) ok += confusion[i * IAO_NUM_CLASSES + i];
+    *accuracy = ok / (float)n; /* :229-236 */
+    float tp = 0, tr = 0;
+    for (int i = 0; i < IAO_NUM_CLASSES; i++) { /* :239-255 */
+        int row = 0, col = 0;
+        for (int j = 0; j < IAO_NUM_CLASSES; j++) {
+            col += confusion[i + j * IAO_NUM_CLASSES];
+            row += confusion[i * IAO_NUM_CLASSES + j];
+        }
+        int t = confusion[i * IAO_NUM_CLASSES + i];
+        tp += (row > 0) ? t / (float)row : 0;
+        tr += (col > 0) ? t / (float)col : 0;
+    }
+    *precision = tp / IAO_NUM_CLASSES;
+    *recall = tr / IAO_NUM_CLASSES;
+}
+
 float iao_knn_crossval(const float *dataset, int numInstances, int A, int k, float *precision, float *recall,
                        float *fold_accuracy) {
     int numToRotate = (int)(numInstances * .1); /* :262 */
@@ -792,27 +861,7 @@ float iao_knn_crossval(const float *dataset, int numInstances, int A, int k, flo
             const float *test = rot + (long)trainSize * A;
             iao_knn_predict(rot, test, trainSize, numToRotate, A, k, pred);
             int confusion[IAO_NUM_CLASSES * IAO_NUM_CLASSES];
-            memset(confusion, 0, sizeof confusion);
-            for (int i = 0; i < numToRotate; i++) { /* :214-227 */
-                int tc = (int)test[(long)i * A + A - 1], pc = pred[i];
-                if (tc >= 0 && tc < IAO_NUM_CLASSES && pc >= 0 && pc < IAO_NUM_CLASSES) confusion[tc * IAO_NUM_CLASSES + pc]++;
-            }
-            int ok = 0;
-            for (int i = 0; i < IAO_NUM_CLASSES; i++) ok += confusion[i * IAO_NUM_CLASSES + i];
-            accuracy = ok / (float)numToRotate; /* :229-236 */
-            float tp = 0, tr = 0;
-            for (int i = 0; i < IAO_NUM_CLASSES; i++) { /* :239-255 */
-                int row = 0, col = 0;
-                for (int j = 0; j < IAO_NUM_CLASSES; j++) {
-                    col += confusion[i + j * IAO_NUM_CLASSES];
-                    row += confusion[i * IAO_NUM_CLASSES + j];
-                }
-                int t = confusion[i * IAO_NUM_CLASSES + i];
-                tp += (row > 0) ? t / (float)row : 0;
-                tr += (col > 0) ? t / (float)col : 0;
-            }
-            prec = tp / IAO_NUM_CLASSES;
-            rec = tr / IAO_NUM_CLASSES;
+            iao_confusion_metrics(pred, test, A, numToRotate, confusion, &accuracy, &prec, &rec);
         }
         if (fold_accuracy) fold_accuracy[fold] = accuracy;
         totalAccuracy += (double)accuracy;

@@ -5,9 +5,16 @@
  * layer, the pipeline driver) may link or call this file; only tests/, the
  * smoke check and the cpu_baseline leg of bench.py do, and only as the checker.
  *
- * PARITY UNPINNED: the reference holds no golden vectors, known-answer tests
- * or fixtures, and it cannot be built here (CUDA, cuRAND, Thrust, OpenCV,
- * jsoncpp are absent).  Every function below restates the reference source
+ * PARITY UNPINNED for everything that lives in a CUDA kernel or a CUDA-calling
+ * wrapper: the reference holds no golden vectors, known-answer tests or
+ * fixtures, and its kernels cannot be built here (CUDA, cuRAND, Thrust, OpenCV,
+ * jsoncpp are absent).  REFERENCE-PINNED are the functions the reference
+ * keeps as plain host code, which g++ compiles unmodified from its sources
+ * (oracle/ref_host/): iao_eq_map, the rand()-based centroid draws,
+ * iao_centroids_changed, iao_array_sum, the four histogram features and the
+ * cross-validation metrics are checked against vectors made by running that
+ * code (tests/golden/ref_host.npz, tests/test_ref_host_golden.py).
+ * Every function below restates the reference source
  * text (cited per function as imageAnalysis.cu:line) as one scalar "logical
  * thread per pixel" loop.  Where the reference is racy, reads out of bounds or
  * relies on undefined casts, the resolution used here is stated at the
@@ -55,6 +62,10 @@ int iao_otsu(const uint8_t *in, uint8_t *out, int W, int H);
 void iao_mean_std(const uint8_t *in, long N, float *mean, float *stddev);
 /* Same statistics from a full 256-bin histogram (bin 0 included). */
 void iao_mean_std_from_hist(const long long *cnt, long N, float *mean, float *stddev);
+/* The same two with the pixel sum handed in, so that tests can ask what another value of the
+ * reference's order-unspecified float sum (imageAnalysis.cu:111-115,250-254) would change. */
+void iao_mean_std_from_hist_sum(const long long *cnt, long N, long long sum, float *mean, float *stddev);
+int iao_otsu_from_hist(const int *hist, long long sum, int numPixels);
 
 /* ---- random numbers ------------------------------------------------------ */
 /* XORWOW as initialised by curand_init(seed, subsequence=tid, offset=0)
@@ -113,6 +124,21 @@ void iao_erode(const uint8_t *in, uint8_t *out, int W, int H, const int *se, int
  * never zeroes them).  Returns iterations run. */
 int iao_kmeans2(const uint8_t *in, uint8_t *out, long N, int c0, int c1);
 /* imageMachineLearning.cu:341-422: mean,std,area,perimeter,mode,rangeMin,rangeMax */
+/* The reference's small host-only functions, kept as functions of their own so that the
+ * vectors made by running the reference's own code (tests/golden/ref_host.npz) pin them:
+ * centroidsHaveChanged (imageAnalysis.cu:281-293), random (:39-41) on one rand() value, arraySum
+ * (:682-688), calcMode / calculateCellArea / calculateCellPerimeter / calcMinAndMaxOfRange
+ * (imageMachineLearning.cu:341-391), and the confusion-matrix metrics (:214-255; 6 classes,
+ * rows whose class falls outside are left out instead of written out of bounds). */
+int iao_centroids_changed(uint8_t *cent, int k);
+int iao_random_from_rand(int lo, int hi, int rand_value);
+int iao_array_sum(const int *a, int n);
+int iao_hist_mode(const int *hist);
+int iao_hist_area(const int *hist, int numPixels);
+int iao_hist_perimeter(const int *hist);
+void iao_hist_range(const int *hist, int *rmin, int *rmax);
+void iao_confusion_metrics(const int *pred, const float *rows, int numAttributes, int n, int *confusion36,
+                           float *accuracy, float *precision, float *recall);
 void iao_features(const uint8_t *in, int W, int H, float *feat7);
 
 /* ---- whole pipelines, for the CPU baseline and executor parity ------------- */

@@ -298,3 +298,47 @@ def test_pipeline_equals_op_by_op():
         y = O.sobel(O.median(O.salt_pepper(O.gauss_noise(O.equalize(g), x0), x0, x1, 50), [1] * 9, 3, 3))
         assert np.array_equal(out[b], y)
     assert np.array_equal(hs, total)
+
+
+def test_float_sum_perturbation_of_gauss_table_and_otsu():
+    """The reference adds the pixels up in float32 in an order Thrust does not define
+    (imageAnalysis.cu:111-115, 250-254); here the sum is the exact integer.  For 768x568 images
+    the sum lies above 2^24, so the reference's value can be off by a few float32 steps.  What
+    that does downstream, measured on the synthetic image kinds: a perturbation of the sum by
+    +-1 and +-4 float32 steps leaves the Otsu threshold where it is and moves at most a few
+    entries of the 256-entry Gaussian amplitude table by one grey level."""
+    import ctypes as C
+    L = O.lib()
+    i64p = np.ctypeslib.ndpointer(np.int64, flags="C")
+    i32p = np.ctypeslib.ndpointer(np.int32, flags="C")
+    L.iao_mean_std_from_hist_sum.argtypes = [i64p, C.c_long, C.c_longlong, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.iao_otsu_from_hist.argtypes = [i32p, C.c_longlong, C.c_int]
+    L.iao_otsu_from_hist.restype = C.c_int
+    W, H = 768, 568
+    N = W * H
+    worst_entries, worst_step, thr_moves = 0, 0, 0
+    for kind, idx in [("C", 0), ("C", 1), ("C", 2), ("U", 0), ("U", 1)]:
+        img = synth.gray_image(kind, W, H, idx)
+        cnt = np.bincount(img.reshape(-1), minlength=256).astype(np.int64)
+        hist = cnt.astype(np.int32)
+        hist[0] = 0
+        total = int((cnt * np.arange(256)).sum())
+        assert total > 2 ** 24
+        ulp = int(np.spacing(np.float32(total)))
+
+        def outputs(s):
+            m, sd = C.c_float(), C.c_float()
+            L.iao_mean_std_from_hist_sum(cnt, N, s, C.byref(m), C.byref(sd))
+            return O.gauss_table(m.value, np.float32(sd.value) * np.float32(sd.value)), L.iao_otsu_from_hist(hist, s, N)
+
+        base_table, base_thr = outputs(total)
+        assert base_thr == O.otsu(img)[1]
+        for steps in (-4, -1, 1, 4):
+            table, thr = outputs(total + steps * ulp)
+            diff = np.abs(table.astype(int) - base_table.astype(int))
+            diff = np.minimum(diff, 256 - diff)
+            worst_entries = max(worst_entries, int((diff != 0).sum()))
+            worst_step = max(worst_step, int(diff.max()))
+            thr_moves += int(thr != base_thr)
+    assert thr_moves == 0
+    assert worst_step <= 1 and worst_entries <= 4, (worst_entries, worst_step)
