@@ -1,6 +1,6 @@
 // ia_driver -- the reference's test driver (test/test.cu:194-705) on this library.
 //
-//   ia_driver <config.json> [--per-image | --batch] [--batch-size N] [--check-config]
+//   ia_driver <config.json> [--per-image | --batch] [--batch-size N] [--gpus N] [--check-config]
 //
 // Reads the same JSON config (image_folder, input_image_filter, output_dir, extract_channel,
 // saveFinalImages, saveIntermediateImages, calc_MSQE, knn, operations[...]), walks the folder
@@ -10,6 +10,11 @@
 //                as one batch per image size and runs the whole operation list through the
 //                batched executor (iak_pipeline_*): no per-operation allocation, copy or
 //                synchronisation.
+//   --gpus N     (batched flow) cuts the sorted file list into N contiguous shares, one host thread
+//                and one device per share; feature rows, labels and the data-set histogram are
+//                merged on the host in file order, so the CSV is the one-device CSV.
+//                --share-devices lets N exceed the number of GPUs (shares then take devices in
+//                turn): a rehearsal of the sharding on a smaller machine.
 //   --per-image  the reference's own flow, call for call, through imageAnalysis.h: one image
 //                at a time, one allocation per operation, previous image freed by the driver.
 //                Chosen automatically when the config asks for what only that flow has:
@@ -25,6 +30,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
+#include <functional>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -32,6 +39,7 @@
 #include <regex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/iak.h"
@@ -396,49 +404,37 @@ int run_per_image(const Config &c, const vector<string> &files, vector<Op> &ops)
 }
 
 // ---- the batched flow ---------------------------------------------------------------------------------------
-int run_batched(const Config &c, const vector<string> &files, vector<Op> &ops, int batch_size) {
-    // the executor takes every operation of the list or none: an unknown type is reported and
-    // skipped, as the reference's loop does
-    vector<iak_op> plan;
-    bool has_features = false;
-    for (Op &op : ops) {
-        const int code = executor_code(op.type);
-        if (!code) {
-            printf("Unsupported Operation\n");
-            continue;
-        }
-        iak_op o{};
-        o.type = code;
-        o.kW = op.kW;
-        o.kH = op.kH;
-        o.fkernel = op.fk.empty() ? nullptr : op.fk.data();
-        o.ikernel = op.ik.empty() ? nullptr : op.ik.data();
-        o.iparam = op.iparam;
-        o.mean = op.mean;
-        o.stddev = op.stddev;
-        plan.push_back(o);
-        has_features = has_features || code == IAK_OP_FEATURES;
-    }
-    const int input = c.extract_channel == "grey" ? IAK_INPUT_LUMINANCE : c.extract_channel == "red" ? IAK_INPUT_RED
-                      : c.extract_channel == "green" ? IAK_INPUT_GREEN : c.extract_channel == "blue" ? IAK_INPUT_BLUE : -1;
-    if (input < 0) {  // test/test.cu:319-322
-        printf("Unsupported color option: %s\n", c.extract_channel.c_str());
-        exit(-10);
-    }
-    Classes classes;
-    vector<vector<float>> dataset;
-    vector<int> labels;
+// What one device makes of its contiguous share of the file list.
+struct ShardResult {
+    vector<string> files;            // one per feature row, in row order
+    vector<vector<float>> rows;      // feature rows
     double n_images = 0, pipeline_ms = 0, load_ms = 0, save_ms = 0;
-    const auto t_all = std::chrono::steady_clock::now();
+    unsigned long long hist[256];    // dataset histogram of the grayscale / channel images (value 0 not counted)
+};
 
+struct BatchPlan {
+    vector<iak_op> ops;
+    bool has_features = false;
+    int n_kmeans = 0;
+    int input = 0;
+};
+
+// files[lo, hi) on `device`: loads the images, keeps them on the device as one batch per image
+// size and runs the whole operation list through the batched executor.
+void run_shard(const Config &c, const vector<string> &files, size_t lo, size_t hi, const BatchPlan &plan, int batch_size,
+               int device, ShardResult *res) {
+    DRV_CHECK(iak_set_device(device));
+    memset(res->hist, 0, sizeof res->hist);
     // One executor per image size, created when the first image of that size shows up; the k-means
     // centroid stream is the executor's, so a folder of equally sized images (the data set's case)
-    // sees the same draws as the per-image flow.
+    // sees the same draws as the per-image flow -- a shard that starts at file `lo` first moves
+    // that stream past the `lo` images before it.
     struct Lane {
         int W = 0, H = 0;
         iak_pipeline *pipe = nullptr;
         uint8_t *d_rgb = nullptr, *d_out = nullptr;
         float *d_feat = nullptr;
+        unsigned long long *d_hist = nullptr;
         std::unique_ptr<uint8_t[]> h_rgb, h_out;  // not value-initialised: hundreds of megabytes
         vector<float> h_feat;
         vector<string> pending;
@@ -450,9 +446,9 @@ int run_batched(const Config &c, const vector<string> &files, vector<Op> &ops, i
         const size_t N = (size_t)L.W * L.H;
         auto t0 = std::chrono::steady_clock::now();
         DRV_CHECK(iak_memcpy_h2d(L.d_rgb, L.h_rgb.get(), 3 * N * (size_t)B, nullptr));
-        DRV_CHECK(iak_pipeline_run(L.pipe, L.d_rgb, L.d_out, B, nullptr, nullptr, nullptr));
+        DRV_CHECK(iak_pipeline_run(L.pipe, L.d_rgb, L.d_out, B, L.d_hist, nullptr, nullptr));
         DRV_CHECK(iak_stream_sync(nullptr));
-        pipeline_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        res->pipeline_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         t0 = std::chrono::steady_clock::now();
         if (c.save_final) {
             DRV_CHECK(iak_memcpy_d2h(L.h_out.get(), L.d_out, N * (size_t)B, nullptr));
@@ -462,18 +458,19 @@ int run_batched(const Config &c, const vector<string> &files, vector<Op> &ops, i
                 if (!err.empty()) fprintf(stderr, "%s: %s\n", path.c_str(), err.c_str());
             }
         }
-        if (has_features) {
+        if (plan.has_features) {
             DRV_CHECK(iak_memcpy_d2h(L.h_feat.data(), L.d_feat, sizeof(float) * IAK_N_FEATURES * (size_t)B, nullptr));
             for (int b = 0; b < B; b++) {
-                dataset.emplace_back(L.h_feat.begin() + IAK_N_FEATURES * b, L.h_feat.begin() + IAK_N_FEATURES * (b + 1));
-                labels.push_back(classes.label_of(L.pending[b]));
+                res->rows.emplace_back(L.h_feat.begin() + IAK_N_FEATURES * b, L.h_feat.begin() + IAK_N_FEATURES * (b + 1));
+                res->files.push_back(L.pending[b]);
             }
         }
-        save_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        n_images += B;
+        res->save_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        res->n_images += B;
         L.pending.clear();
     };
-    for (const string &file : files) {
+    for (size_t f = lo; f < hi; f++) {
+        const string &file = files[f];
         auto t0 = std::chrono::steady_clock::now();
         bmp_io::Planar img;
         const string err = bmp_io::read(c.image_folder + "/" + file, &img);
@@ -492,13 +489,17 @@ int run_batched(const Config &c, const vector<string> &files, vector<Op> &ops, i
             L->W = img.width;
             L->H = img.height;
             const size_t N = (size_t)L->W * L->H;
-            DRV_CHECK(iak_pipeline_create(&L->pipe, L->W, L->H, batch_size, plan.data(), (int)plan.size(), 1234ULL, IAK_PIPE_FUSED));
-            DRV_CHECK(iak_pipeline_set_input(L->pipe, input));
+            DRV_CHECK(iak_pipeline_create(&L->pipe, L->W, L->H, batch_size, plan.ops.data(), (int)plan.ops.size(), 1234ULL,
+                                          IAK_PIPE_FUSED));
+            DRV_CHECK(iak_pipeline_set_input(L->pipe, plan.input));
+            DRV_CHECK(iak_pipeline_skip_images(L->pipe, (long long)lo, nullptr));
             DRV_CHECK(iak_malloc((void **)&L->d_rgb, 3 * N * (size_t)batch_size));
             DRV_CHECK(iak_malloc((void **)&L->d_out, N * (size_t)batch_size));
+            DRV_CHECK(iak_malloc((void **)&L->d_hist, 256 * sizeof(unsigned long long)));
+            DRV_CHECK(iak_memset(L->d_hist, 0, 256 * sizeof(unsigned long long), nullptr));
             L->h_rgb.reset(new uint8_t[3 * N * (size_t)batch_size]);
             L->h_out.reset(new uint8_t[N * (size_t)batch_size]);
-            if (has_features) {
+            if (plan.has_features) {
                 DRV_CHECK(iak_malloc((void **)&L->d_feat, sizeof(float) * IAK_N_FEATURES * (size_t)batch_size));
                 DRV_CHECK(iak_pipeline_bind_features(L->pipe, L->d_feat));
                 L->h_feat.resize((size_t)IAK_N_FEATURES * batch_size);
@@ -507,25 +508,135 @@ int run_batched(const Config &c, const vector<string> &files, vector<Op> &ops, i
         const size_t N = (size_t)L->W * L->H;
         memcpy(L->h_rgb.get() + 3 * N * L->pending.size(), img.rgb.data(), 3 * N);
         L->pending.push_back(file);
-        load_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        res->load_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if ((int)L->pending.size() == batch_size) flush(*L);
     }
     for (Lane &L : lanes) flush(L);
     for (Lane &L : lanes) {
+        unsigned long long h[256];
+        DRV_CHECK(iak_memcpy_d2h(h, L.d_hist, sizeof h, nullptr));
+        for (int v = 0; v < 256; v++) res->hist[v] += h[v];
         DRV_CHECK(iak_pipeline_destroy(L.pipe));
         DRV_CHECK(iak_free(L.d_rgb));
         DRV_CHECK(iak_free(L.d_out));
+        DRV_CHECK(iak_free(L.d_hist));
         if (L.d_feat) DRV_CHECK(iak_free(L.d_feat));
+    }
+}
+
+// The folder is cut into `gpus` contiguous shares (the first n % gpus shares hold one file more),
+// one host thread per device runs its share, and the host merges what the reference keeps at
+// data-set level: the feature rows with their class labels in file order (test/test.cu:541-550)
+// and the 256-bin histogram (test/test.cu:407-411).  The payload is a few KiB per device, so
+// the merge is a host loop, not a collective.  *images_done: images that went through.
+int run_batched(const Config &c, const vector<string> &files, vector<Op> &ops, int batch_size, int gpus, bool share_devices,
+                double *images_done) {
+    // the executor takes every operation of the list or none: an unknown type is reported and
+    // skipped, as the reference's loop does
+    BatchPlan plan;
+    for (Op &op : ops) {
+        const int code = executor_code(op.type);
+        if (!code) {
+            printf("Unsupported Operation\n");
+            continue;
+        }
+        iak_op o{};
+        o.type = code;
+        o.kW = op.kW;
+        o.kH = op.kH;
+        o.fkernel = op.fk.empty() ? nullptr : op.fk.data();
+        o.ikernel = op.ik.empty() ? nullptr : op.ik.data();
+        o.iparam = op.iparam;
+        o.mean = op.mean;
+        o.stddev = op.stddev;
+        plan.ops.push_back(o);
+        plan.has_features = plan.has_features || code == IAK_OP_FEATURES;
+        plan.n_kmeans += code == IAK_OP_KMEANS ? 1 : 0;
+    }
+    plan.input = c.extract_channel == "grey" ? IAK_INPUT_LUMINANCE : c.extract_channel == "red" ? IAK_INPUT_RED
+                 : c.extract_channel == "green" ? IAK_INPUT_GREEN : c.extract_channel == "blue" ? IAK_INPUT_BLUE : -1;
+    if (plan.input < 0) {  // test/test.cu:319-322
+        printf("Unsupported color option: %s\n", c.extract_channel.c_str());
+        exit(-10);
+    }
+    int n_devices = 0;
+    DRV_CHECK(iak_device_count(&n_devices));
+    if (gpus > n_devices && !share_devices) {
+        fprintf(stderr, "--gpus %d: this machine has %d GPU(s)\n", gpus, n_devices);
+        return 2;
+    }
+    const auto t_all = std::chrono::steady_clock::now();
+    vector<ShardResult> shard((size_t)gpus);
+    vector<std::thread> workers;
+    const size_t n = files.size(), base = n / (size_t)gpus, extra = n % (size_t)gpus;
+    for (int g = 0; g < gpus; g++) {
+        const size_t lo = (size_t)g * base + std::min((size_t)g, extra);
+        const size_t hi = lo + base + ((size_t)g < extra ? 1 : 0);
+        const int per = std::max<size_t>(1, std::min<size_t>((size_t)batch_size, hi - lo));
+        workers.emplace_back(run_shard, std::cref(c), std::cref(files), lo, hi, std::cref(plan), per, g % n_devices, &shard[(size_t)g]);
+    }
+    for (auto &w : workers) w.join();
+    // merge, shard by shard = in file order
+    Classes classes;
+    vector<vector<float>> dataset;
+    vector<int> labels;
+    unsigned long long hist[256] = {0};
+    double n_images = 0, pipeline_ms = 0, load_ms = 0, save_ms = 0;
+    for (const ShardResult &r : shard) {
+        for (size_t k = 0; k < r.rows.size(); k++) {
+            dataset.push_back(r.rows[k]);
+            labels.push_back(classes.label_of(r.files[k]));
+        }
+        for (int v = 0; v < 256; v++) hist[v] += r.hist[v];
+        n_images += r.n_images;
+        pipeline_ms = std::max(pipeline_ms, r.pipeline_ms);  // the devices run side by side
+        load_ms = std::max(load_ms, r.load_ms);
+        save_ms = std::max(save_ms, r.save_ms);
     }
     if (!c.features_csv.empty() && !dataset.empty()) write_csv(c.features_csv, dataset, labels);
     const double all_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count();
-    const double n = n_images > 0 ? n_images : 1;
-    printf("\n\nTotal time spent on the entire batch: %0.4f ms average of %0.4f ms for each image\n", all_ms, all_ms / n);
-    printf("Total time spent reading and decoding images: %0.4f ms average of: %0.4f ms per image\n", load_ms, load_ms / n);
+    const double nn = n_images > 0 ? n_images : 1;
+    printf("\n\nTotal time spent on the entire batch: %0.4f ms average of %0.4f ms for each image\n", all_ms, all_ms / nn);
+    printf("Total time spent reading and decoding images: %0.4f ms average of: %0.4f ms per image\n", load_ms, load_ms / nn);
     printf("Total time spent copying to the device and running all operations: %0.4f ms average of: %0.4f ms per image\n",
-           pipeline_ms, pipeline_ms / n);
+           pipeline_ms, pipeline_ms / nn);
     printf("Total time spent copying back, encoding and writing results: %0.4f ms average of: %0.4f ms per image\n", save_ms,
-           save_ms / n);
+           save_ms / nn);
+    // data-set level sums (the reference keeps totalHist, compiled out, and the per-class rows)
+    unsigned long long counted = 0, weighted = 0;
+    for (int v = 0; v < 256; v++) {
+        counted += hist[v];
+        weighted += hist[v] * (unsigned long long)v;
+    }
+    printf("Dataset histogram over %d device(s): %llu non-zero pixels in %.0f images, mean of those %0.4f\n", gpus, counted,
+           n_images, counted ? (double)weighted / (double)counted : 0.0);
+    if (plan.has_features) {
+        vector<string> names(classes.ids.size());
+        for (auto &kv : classes.ids) names[(size_t)kv.second] = kv.first;
+        for (size_t k = 0; k < names.size(); k++) {
+            double cnt = 0, s[IAK_N_FEATURES] = {0}, ss[IAK_N_FEATURES] = {0};
+            for (size_t r = 0; r < dataset.size(); r++)
+                if (labels[r] == (int)k) {
+                    cnt += 1;
+                    for (int f = 0; f < IAK_N_FEATURES; f++) {
+                        s[f] += dataset[r][f];
+                        ss[f] += (double)dataset[r][f] * dataset[r][f];
+                    }
+                }
+            printf("class %zu '%s': %.0f images; mean / std of", k, names[k].c_str(), cnt);
+            static const char *fname[IAK_N_FEATURES] = {"mean", "stddev", "area", "perimeter", "mode", "rangeMin", "rangeMax"};
+            for (int f = 0; f < IAK_N_FEATURES; f++) {
+                const double m = cnt ? s[f] / cnt : 0, var = cnt ? std::max(0.0, ss[f] / cnt - m * m) : 0;
+                printf(" %s %0.3f / %0.3f%s", fname[f], m, sqrt(var), f + 1 < IAK_N_FEATURES ? "," : "\n");
+            }
+        }
+    }
+    *images_done = n_images;
+    // The per-image flow has drawn two rand() values per image per k-means operation by now
+    // (imageAnalysis.cu:359-361); here the executors drew them on the device.  Bring the host
+    // stream to the same point, so that what follows (the shuffle of the cross-validation data,
+    // test/test.cu:165) sees the same values in both flows.
+    for (long long k = 0; k < 2LL * plan.n_kmeans * (long long)n_images; k++) (void)rand();
     return 0;
 }
 
@@ -537,14 +648,16 @@ int main(int argc, char *argv[]) {
         exit(-1);
     }
     string config_path;
-    bool force_per_image = false, force_batch = false, check_only = false;
-    int batch_size = 512;
+    bool force_per_image = false, force_batch = false, check_only = false, share_devices = false;
+    int batch_size = 512, gpus = 1;
     for (int i = 1; i < argc; i++) {
         const string a = argv[i];
         if (a == "--per-image") force_per_image = true;
         else if (a == "--batch") force_batch = true;
         else if (a == "--check-config") check_only = true;
         else if (a == "--batch-size" && i + 1 < argc) batch_size = atoi(argv[++i]);
+        else if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (a == "--share-devices") share_devices = true;
         else if (config_path.empty()) config_path = a;
         else {
             fprintf(stderr, "unexpected argument %s\n", a.c_str());
@@ -552,6 +665,7 @@ int main(int argc, char *argv[]) {
         }
     }
     if (batch_size < 1) batch_size = 1;
+    if (gpus < 1) gpus = 1;
     Config c;
     try {
         c = read_config(config_path);
@@ -594,7 +708,13 @@ int main(int argc, char *argv[]) {
         srand(1);
     }
     if ((size_t)batch_size > files.size()) batch_size = files.empty() ? 1 : (int)files.size();
-    const int rc = (force_per_image || needs_per_image) ? run_per_image(c, files, ops) : run_batched(c, files, ops, batch_size);
+    if (gpus > 1 && (force_per_image || needs_per_image)) {
+        fprintf(stderr, "--gpus: only the batched flow shards the folder over devices\n");
+        return 2;
+    }
+    double images_done = 0;
+    const int rc = (force_per_image || needs_per_image) ? run_per_image(c, files, ops)
+                                                        : run_batched(c, files, ops, batch_size, gpus, share_devices, &images_done);
     if (rc == 0 && c.knn) run_knn(c);  // after the batch, as the reference does (test/test.cu:587)
     return rc;
 }

@@ -1111,6 +1111,18 @@ int iak_pipeline_bind_features(iak_pipeline *p, float *features) {
     return 0;
 }
 
+int iak_pipeline_skip_images(iak_pipeline *p, long long images, void *stream) {
+    if (!p || images < 0) return IAK_E_ARG;
+    if (!p->n_kmeans) return 0;  // nothing in this pipeline depends on how many images came before
+    while (images > 0) {  // draw and drop, one batch's worth at a time (kmeans_init holds maxB images)
+        const int n = images > p->maxB ? p->maxB : (int)images;
+        const int rc = iak_glibc_rand_centroids(p->rand_state, n, p->n_kmeans, p->kmeans_init, stream);
+        if (rc) return rc;
+        images -= n;
+    }
+    return 0;
+}
+
 int iak_pipeline_timed_images(iak_pipeline *p) { return p ? p->timed_images : IAK_E_ARG; }
 
 int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, unsigned long long *hist_sum,

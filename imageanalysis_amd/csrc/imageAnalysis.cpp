@@ -2,7 +2,9 @@
 // on top of the C ABI of libiak.so.  Each function keeps the reference wrapper's contract:
 // the callee allocates output->image on the device and sets width/height, the caller frees
 // the previous image; failures of the runtime print and exit(1).  Single images are batches
-// of one.  Nothing here computes on pixels: that is all behind iak.h.
+// of one.  Nothing here computes on pixels or histograms: that is all behind iak.h; what stays
+// on the host is what the reference keeps on the host (equalizeHistogram's 256-entry loop, the
+// rand() draws, the cross-validation bookkeeping).
 #include "../../include/imageAnalysis.h"
 #include "../../include/imageMachineLearning.h"
 #include "../../include/iak.h"
@@ -35,6 +37,7 @@ struct Scratch {
     int32_t *map = nullptr;     // 256
     uint16_t *table = nullptr;  // 256
     int32_t *thr = nullptr;     // 1
+    int32_t *cent = nullptr;    // 2: initial k-means centroids
     float *ms = nullptr;        // 2
     uint32_t *sum = nullptr;    // 1
     float *feat = nullptr;      // 7
@@ -46,6 +49,7 @@ struct Scratch {
         IAK_CHECK(iak_malloc((void **)&map, 256 * sizeof(int32_t)));
         IAK_CHECK(iak_malloc((void **)&table, 256 * sizeof(uint16_t)));
         IAK_CHECK(iak_malloc((void **)&thr, sizeof(int32_t)));
+        IAK_CHECK(iak_malloc((void **)&cent, 2 * sizeof(int32_t)));
         IAK_CHECK(iak_malloc((void **)&ms, 2 * sizeof(float)));
         IAK_CHECK(iak_malloc((void **)&sum, sizeof(uint32_t)));
         IAK_CHECK(iak_malloc((void **)&feat, IAK_N_FEATURES * sizeof(float)));
@@ -195,51 +199,18 @@ static int reference_random(int min, int max) {  // imageAnalysis.cu:39-41
 }
 
 void kMeansThresholding(Image *image, Image *output) {
-    // imageAnalysis.cu:351-379.  A pixel's label depends on its value only, so the class
-    // sums and counts of every iteration come from the 256-bin histogram: one histogram
-    // pass and one table pass over the image instead of two passes per iteration.
+    // imageAnalysis.cu:351-379.  A pixel's label depends on its value only, so the iterations run
+    // on the 256-bin histogram (iak_kmeans2_map) and the image is touched by one histogram pass
+    // and one table pass.  The two initial centroids are this process's next two rand() draws,
+    // as in the reference (:359-361).
     g_scratch.ensure();
     alloc_like(image, output);
     const long long n = pixels(image);
-    int h[256];
+    const int32_t cent[2] = {reference_random(0, 256), reference_random(0, 256)};
+    IAK_CHECK(iak_memcpy_h2d(g_scratch.cent, cent, sizeof cent, nullptr));
     IAK_CHECK(iak_hist(image->image, g_scratch.hist, n, 1, n, nullptr));
-    IAK_CHECK(iak_memcpy_d2h(h, g_scratch.hist, sizeof h, nullptr));
-    long long nonzero = 0;
-    for (int v = 1; v < 256; v++) nonzero += h[v];
-    h[0] = (int)(n - nonzero);
-    const int k = 2;
-    unsigned char cent[4];
-    for (int i = 0; i < k; i++) cent[i] = (unsigned char)reference_random(0, 256);
-    int count = 0;
-    bool changed;
-    int label[256];
-    do {
-        unsigned int sums[2] = {0, 0};  // the reference never zeroes these (:321-325)
-        int counts[2] = {0, 0};
-        for (int v = 0; v < 256; v++) {
-            label[v] = (abs(cent[0] - v) > abs(cent[1] - v)) ? 0 : 1;  // :298-302
-            sums[label[v]] += (unsigned int)v * (unsigned int)h[v];
-            counts[label[v]] += h[v];
-        }
-        for (int i = 0; i < k; i++) {
-            const float q = floorf(sums[i] / (float)counts[i]);  // :332; 0/0 -> NaN -> 0
-            cent[i + k] = (q != q) ? 0 : (unsigned char)(int)q;
-        }
-        count++;
-        changed = false;
-        for (int i = 0; i < k; i++)
-            if ((cent[i] ^ cent[i + k]) != 0) {
-                cent[i] = cent[i + k];
-                changed = true;
-            }
-    } while (changed && count < 100);
-    int levels[256 * 3];
-    for (int v = 0; v < 256; v++) {  // applyLabels (:339-349) as a table
-        levels[3 * v] = v;
-        levels[3 * v + 1] = v + 1;
-        levels[3 * v + 2] = label[v] == 0 ? 0 : 255;
-    }
-    IAK_CHECK(iak_quantize(image->image, output->image, n, 1, n, n, levels, 256, nullptr));
+    IAK_CHECK(iak_kmeans2_map(g_scratch.hist, (int)n, 1, g_scratch.cent, g_scratch.map, nullptr, nullptr));
+    IAK_CHECK(iak_apply_map(image->image, output->image, n, 1, n, n, g_scratch.map, 256, nullptr));
 }
 
 void kMeansThresholding(Image *image, Image *output, int k) {

@@ -77,6 +77,7 @@ SIGNATURES = {
     "iak_pipeline_destroy": [_vp],
     "iak_pipeline_run": [_vp, _vp, _vp, _i, _vp, _vp, _vp],
     "iak_pipeline_set_lanes": [_vp, _i],
+    "iak_pipeline_skip_images": [_vp, _ll, _vp],
     "iak_pipeline_timed_images": [_vp],
     "iak_pipeline_set_timing": [_vp, _i],
     "iak_pipeline_set_timing_every": [_vp, _i],

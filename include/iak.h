@@ -307,6 +307,12 @@ int iak_pipeline_set_lanes(iak_pipeline *p, int lanes);
 /* Where IAK_OP_FEATURES writes: DEVICE float[maxB][7], image b of a run at features + 7 * b.
  * Required before running a pipeline that has that operation. */
 int iak_pipeline_bind_features(iak_pipeline *p, float *features);
+/* Tells a new pipeline that `images` images of the data set come before the first one it will
+ * see: the k-means centroid draws (two libc rand() values per image per k-means operation, in
+ * image order, test/test.cu:266 + imageAnalysis.cu:359-361) continue from there.  This is what
+ * lets a shard of a folder that starts at image i0 produce what the serial loop produces for
+ * those images.  No effect on pipelines without IAK_OP_KMEANS. */
+int iak_pipeline_skip_images(iak_pipeline *p, long long images, void *stream);
 /* Number of images the timed sub-batch of the most recent run held (all of them with 1 lane). */
 int iak_pipeline_timed_images(iak_pipeline *p);
 /* Per-launch-group timing.  set_timing(p, slots) (re)creates `slots` sets of HIP events

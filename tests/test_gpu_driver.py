@@ -109,3 +109,53 @@ def test_driver_colour_channel(folder, mode):
     cent = O.libc_random_0_256(2 * len(NAMES)).reshape(len(NAMES), 1, 2)
     want, _, feats = O.pipeline_ex(rgb, OPS, x0, x1, centroids=cent, input=3)
     check_outputs(out, want, feats)
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_driver_shards_the_folder_over_devices(folder, gpus):
+    """--gpus N cuts the file list into N contiguous shares, one host thread each (on this box they
+    share the one device).  Images, the CSV with its labels and the k-means draws (a share that
+    starts at file i continues the centroid stream from image i) are the one-device results."""
+    d, rgb, want, feats = folder
+    out, stdout = run_driver(d, ["--batch", "--gpus", str(gpus), "--share-devices"], f"gpus{gpus}")
+    check_outputs(out, want, feats)
+    line = [l for l in stdout.splitlines() if l.startswith("Dataset histogram over")]
+    assert len(line) == 1 and f"over {gpus} device(s)" in line[0]
+    # the data-set histogram: every non-zero grayscale pixel of every image, counted once
+    nonzero = sum(int((O.gray(rgb[i], 0) != 0).sum()) for i in range(len(NAMES)))
+    assert f": {nonzero} non-zero pixels in {len(NAMES)} images" in line[0]
+    classes = [l for l in stdout.splitlines() if l.startswith("class ")]
+    assert len(classes) == 5 and classes[0].startswith("class 0 'cyl': 2 images")
+
+
+def test_driver_refuses_more_gpus_than_the_machine_has(folder):
+    d, _, _, _ = folder
+    out = d / "out_toomany"
+    out.mkdir()
+    cfg = {"image_folder": str(d / "in"), "input_image_filter": "", "saveIntermediateImages": False, "saveFinalImages": False,
+           "calc_MSQE": False, "output_dir": str(out), "extract_channel": "grey", "operations": []}
+    (d / "cfg_toomany.json").write_text(json.dumps(cfg))
+    r = subprocess.run([DRIVER, str(d / "cfg_toomany.json"), "--gpus", "64"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "this machine has" in r.stderr
+
+
+def test_knn_after_kmeans_sees_the_same_rand_stream_in_both_flows(folder):
+    """kMeans-thresh draws its centroids from rand(); the cross-validation shuffles its rows with
+    rand() afterwards (test/test.cu:165,587).  Both flows of the driver must leave the stream at
+    the same point, so the folds and the report agree."""
+    d, _, _, _ = folder
+    rs = np.random.default_rng(5)
+    rows = rs.normal(0, 1, (120, 8)).astype(np.float32) * 10
+    y = rs.integers(0, 5, 120)
+    rows[:, :7] += y[:, None] * 6
+    rows[:, 7] = y
+    csv = d / "knn_in.csv"
+    csv.write_text("".join(",".join(repr(float(v)) for v in r[:-1]) + f",{int(r[-1])}\n" for r in rows))
+    reports = {}
+    for mode in ("--batch", "--per-image"):
+        _, stdout = run_driver(d, [mode], "knn" + mode.strip("-"), {"knn": True, "knnConfig": {"k": 3, "input": str(csv)}})
+        folds = [l for l in stdout.splitlines() if l.startswith("thread ")]
+        last = [l.split(" ms achieved ")[1] for l in stdout.splitlines() if l.startswith("Total time required for a tenfold")]
+        assert len(folds) == 10 and len(last) == 1
+        reports[mode] = (sorted(folds), last[0])
+    assert reports["--batch"] == reports["--per-image"]

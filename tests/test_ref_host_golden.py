@@ -109,3 +109,18 @@ def test_cross_validation_metrics_match_the_reference_functions(L):
         assert np.float32(acc.value) == G["cm_accuracy"][i]
         assert np.float32(prec.value) == G["cm_precision"][i]
         assert np.float32(rec.value) == G["cm_recall"][i]
+
+
+def test_cpp_api_host_equalize_histogram_matches_the_reference_function():
+    """equalizeHistogram of the C++ API layer is host code here as in the reference
+    (imageAnalysis.cu:155-176); no GPU is touched by calling it."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "imageanalysis_amd", "lib", "libimageAnalysis.so")
+    lib = C.CDLL(so)
+    fn = getattr(lib, "_Z17equalizeHistogramPiS_i")
+    fn.argtypes = [i32p, i32p, C.c_int]
+    fn.restype = None
+    for h, n, want in zip(G["eq_hist"], G["eq_num_pixels"], G["eq_map"]):
+        m = np.zeros(256, np.int32)
+        fn(np.ascontiguousarray(h), m, int(n))
+        assert np.array_equal(m, want)
