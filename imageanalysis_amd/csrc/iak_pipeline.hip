@@ -869,6 +869,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
     const Slice sl = slice_of(p, b0);
     rgb += (size_t)b0 * 3 * (size_t)N;
     out += (size_t)b0 * (size_t)N;
+    const bool out_unaligned = p->W % 16 == 0 && !aligned16(out);
     // image-producing groups alternate between the two buffers; the last one writes `out`
     int producers = 0;
     for (auto &g : p->groups)
@@ -881,9 +882,16 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
     for (int gi = 0; gi < ng; gi++) {
         const Group &g = p->groups[gi];
         uint8_t *dst = nullptr;
+        bool copy_out = false;
         if (g.kind != G_HIST && g.kind != G_FEATURES) {
             produced++;
             dst = (produced == producers) ? out : ((produced & 1) ? sl.bufA : sl.bufB);
+            // The fused passes want 16-byte aligned images (W % 16 == 0 plans only).  A caller's `out`
+            // that is not: the last pass writes the executor's own buffer and a copy follows.
+            if (dst == out && out_unaligned) {
+                dst = (produced & 1) ? sl.bufA : sl.bufB;
+                copy_out = true;
+            }
         }
         int rc = 0;
         switch (g.kind) {
@@ -1051,6 +1059,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             break;
         }
         if (rc) return rc;
+        if (copy_out) IAK_HIP(hipMemcpyAsync(out, dst, (size_t)B * (size_t)N, hipMemcpyDeviceToDevice, s));
         if (dst) cur = dst;
         if (ev) IAK_HIP(hipEventRecord(ev[2 * gi + 2], s));
     }

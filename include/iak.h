@@ -296,7 +296,11 @@ int iak_pipeline_set_input(iak_pipeline *p, int input);
 /* rgb: B planar RGB images (stride 3*W*H); out: B result images (stride W*H).
  * hist_sum: DEVICE array of 256 uint64, or NULL; the batch's grayscale-image histogram
  * (bin 0 empty) is ADDED to it -- the dataset histogram a multi-GPU job all-reduces.
- * gray_hist: DEVICE [B][256] uint32 per-image grayscale histograms, or NULL. */
+ * gray_hist: DEVICE [B][256] uint32 per-image grayscale histograms, or NULL.
+ * rgb and out may have any alignment.  The fused passes work on 16-byte aligned images; when
+ * `out` is not (W % 16 == 0 plans), the last pass writes the executor's own buffer and one
+ * device-to-device copy to `out` follows -- allocations of hipMalloc / torch are aligned and
+ * never pay it. */
 int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B,
                      unsigned long long *hist_sum, uint32_t *gray_hist, void *stream);
 /* Cuts every batch into `lanes` (1..8) consecutive sub-batches that run concurrently on

@@ -275,3 +275,31 @@ def test_pipeline_input_modes(Pipeline, what, code, W, H):
     if first is not None:
         for b in range(B):
             assert np.array_equal(gh[b].cpu().numpy(), O.hist(first[b]))
+
+
+@pytest.mark.parametrize("name", ["P-A", "P-C", "sp+median", "otsu+dilate+erode", "thresholded-stencils", "erode3x", "empty"])
+@pytest.mark.parametrize("off_out,off_rgb", [(1, 0), (7, 3), (8, 0), (0, 5)])
+def test_pipeline_takes_buffers_of_any_alignment(Pipeline, name, off_out, off_rgb):
+    """The fused passes want 16-byte aligned images; a caller's buffers that are not (slices of a
+    larger allocation) must still give the same results: the executor stages what it has to."""
+    ops = CHAINS[name]
+    W, H, B = 64, 48, 3
+    rgb = synth.rgb_batch("C", W, H, B)
+    x0, x1 = O.xorwow_planes(W * H)
+    want, want_hist = O.pipeline(rgb, ops, x0, x1)
+    big_in = torch.zeros(rgb.size + 32, dtype=torch.uint8, device="cuda")
+    big_out = torch.full((B * H * W + 32,), 0xAB, dtype=torch.uint8, device="cuda")
+    src = big_in[off_rgb:off_rgb + rgb.size].view(B, 3, H, W)
+    src.copy_(torch.from_numpy(rgb).cuda())
+    dst = big_out[off_out:off_out + B * H * W].view(B, H, W)
+    assert src.data_ptr() % 16 == off_rgb % 16 and dst.data_ptr() % 16 == off_out % 16
+    for fused in (True, "pointwise", False):
+        p = Pipeline(W, H, B, ops, fused=fused)
+        hist_sum = torch.zeros(256, dtype=torch.int64, device="cuda")
+        p.run(src, out=dst, hist_sum=hist_sum)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), want), (name, fused)
+        assert np.array_equal(hist_sum.cpu().numpy(), want_hist)
+        # nothing outside the output range was written
+        assert int((big_out[:off_out] != 0xAB).sum()) == 0 and int((big_out[off_out + B * H * W:] != 0xAB).sum()) == 0
+        p.close()
