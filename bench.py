@@ -351,7 +351,7 @@ class Measurement:
         value = px * world * steps / dt / 1e6
         kernel_of = dict(KERNEL_OF_GROUP, **KERNEL_OF_GROUP_BY_WORKLOAD.get(variant or self.name, {}))
         traffic = _load_profile_json("traffic.json")
-        valu = _load_profile_json("valu.json")
+        valu = _load_profile_json("valu.json").get(variant or self.name, {})
         tpx = timed_images * W * H
         groups = []
         for (n, ms, stage_b, mm), mv in zip(self.groups, moved):
@@ -363,9 +363,9 @@ class Measurement:
                 g["hbm_frac"] = round(gbps / HBM_PEAK_GBS, 4)
                 g["bound"] = "hbm"
                 v = valu.get(kernel_of.get(n, n))
-                if v and v.get("batch") == B:
+                if v and B == WORKLOADS[self.name][3]:  # the counter passes run the default batch
                     # share of the launch during which the vector pipes were issuing, from the SQ counter pass
-                    issue_s = v["valu_busy_cycles_per_launch"] / N_SIMDS / CLOCK_HZ
+                    issue_s = v["valu_busy_simd_cycles_per_launch"] / N_SIMDS / CLOCK_HZ
                     g["valu_issue_frac"] = round(issue_s / (mm * 1e-3), 4)
                     if g["valu_issue_frac"] > g["hbm_frac"]:
                         g["bound"] = "valu"
