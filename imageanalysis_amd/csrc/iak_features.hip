@@ -160,28 +160,29 @@ __global__ __launch_bounds__(256) void dataset_sums_kernel(const unsigned long l
                                                            const float *__restrict__ features,
                                                            const int32_t *__restrict__ labels, int B, int C,
                                                            double *__restrict__ packed) {
-    const int slots = 256 + C * (1 + 2 * FEAT_N);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += gridDim.x * blockDim.x) {
-        if (i < 256) {
-            packed[i] = hist_sum ? (double)hist_sum[i] : 0.0;
-            continue;
-        }
-        const int j = i - 256;
-        double acc = 0.0;
-        if (j < C) {
-            for (int b = 0; b < B; b++) acc += labels[b] == j ? 1.0 : 0.0;
-        } else {
-            const int k = j - C;
-            const bool sq = k >= C * FEAT_N;
-            const int c = (sq ? k - C * FEAT_N : k) / FEAT_N, f = (sq ? k - C * FEAT_N : k) % FEAT_N;
-            for (int b = 0; b < B; b++)
-                if (labels[b] == c) {
-                    const double v = (double)features[(long long)b * FEAT_N + f];
-                    acc += sq ? v * v : v;
-                }
-        }
-        packed[i] = acc;
+    if (blockIdx.x == 0) {  // the histogram, as doubles
+        packed[threadIdx.x] = hist_sum ? (double)hist_sum[threadIdx.x] : 0.0;
+        return;
     }
+    // one wave per output slot: a lane adds up its images (lane, lane + 64, ...) in image order,
+    // then the 64 partial sums are folded in a fixed butterfly -- the same order on every run
+    const int lane = threadIdx.x & 63;
+    const int j = (int)(blockIdx.x - 1) * 4 + (int)(threadIdx.x >> 6);  // slot behind the histogram
+    if (j >= C * (1 + 2 * FEAT_N)) return;
+    double acc = 0.0;
+    if (j < C) {
+        for (int b = lane; b < B; b += 64) acc += labels[b] == j ? 1.0 : 0.0;
+    } else {
+        const int k = j - C;
+        const bool sq = k >= C * FEAT_N;
+        const int c = (sq ? k - C * FEAT_N : k) / FEAT_N, f = (sq ? k - C * FEAT_N : k) % FEAT_N;
+        for (int b = lane; b < B; b += 64) {
+            const double v = (double)features[(long long)b * FEAT_N + f];
+            acc += labels[b] == c ? (sq ? v * v : v) : 0.0;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) packed[256 + j] = acc;
 }
 
 // ---- kMeansThresholding (imageAnalysis.cu:281-379), k = 2, on the histogram ------------------
@@ -475,8 +476,8 @@ int iak_features_static(const uint8_t *img, int W, int H, int B, long long strid
 int iak_dataset_sums(const unsigned long long *hist_sum, const float *features, const int32_t *labels, int B, int C,
                      double *packed, void *stream) {
     if (!packed || B < 0 || C < 0 || C > 4096 || (B > 0 && C > 0 && (!features || !labels))) return IAK_E_ARG;
-    const int slots = 256 + C * (1 + 2 * FEAT_N);
-    hipLaunchKernelGGL(dataset_sums_kernel, dim3((slots + 255) / 256), dim3(256), 0, as_stream(stream), hist_sum, features,
+    const int slots = C * (1 + 2 * FEAT_N);  // behind the 256 histogram bins
+    hipLaunchKernelGGL(dataset_sums_kernel, dim3(1 + (slots + 3) / 4), dim3(256), 0, as_stream(stream), hist_sum, features,
                        labels, B, C, packed);
     IAK_LAUNCH_CHECK();
     return 0;

@@ -461,7 +461,7 @@ int iak_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long i
         }
     }
     if (ones) {
-        rc = launch_huang_median(in, out, W, H, B, in_stride, out_stride, kW, kH, as_stream(stream));
+        rc = launch_column_hist_median(in, out, W, H, B, in_stride, out_stride, kW, kH, as_stream(stream));
         if (rc != IAK_E_UNSUPPORTED) return rc;
     }
     ITaps t;

@@ -333,54 +333,50 @@ static int launch_tiled_morph(const uint8_t *in, uint8_t *out, int W, int H, int
 }
 
 // ---------------------------------------------------------------------------------------
-// Median, all weights 1, kW x kH <= 255 taps: Huang's sliding histogram, one lane per image
-// column.  A lane keeps the 256-bin histogram of its window in LDS (byte counters packed four
-// to a word, word w of lane l at w * LANES + l so that a lane only ever touches bank l % 32)
-// plus four coarse counters (64 values each) in a register; moving down one row takes kW
-// pixels out and kW in, and the median is found from the coarse counters, then the sums of
-// the 16 fine words of that quarter, then one word: O(kW) work per pixel instead of O(kW * kH).
+// Median, all weights 1, kW x kH <= 255 taps: column histograms (after Perreault and Hebert's
+// constant-time median).  One lane per image column, one wave per workgroup, strips of
+// CM_STRIP rows.  A lane keeps the histogram of ITS column's kH rows in LDS -- 256 byte
+// counters packed four to a word plus 16 block counters (16 values each) -- so moving down a
+// row costs one pixel out and one in per lane, whatever kW is.  The window of output column x
+// is columns x-s .. x+s: its block counters and, once the block holding the sought position
+// is known, its 16 fine counters are the byte-wise sums of the neighbouring lanes' words, read
+// straight from LDS (word w of lane l sits at w * CM_LANES + l, so lane l +- k is an immediate
+// offset and every access of a wave instruction goes to bank l % 32: no conflicts, whatever
+// the pixel values are).  The outer s lanes on either side only serve as neighbours, so
+// adjacent workgroups overlap by 2s columns.
 // The result is the smallest v with #(window <= v) > taps/2, i.e. sorted[taps/2]
 // (imageAnalysis.cu:641-680 with a race-free private window).
 // ---------------------------------------------------------------------------------------
-#ifndef HM_LANES
-#define HM_LANES 64
-#endif
-#ifndef HM_STRIP
-#define HM_STRIP 64
-#endif
-#define HM_MAXHALO 24  // kW <= 25
-#define HM_ROWBUF (HM_LANES + HM_MAXHALO + 8)
-// One pixel into (ADD) or out of a lane's histograms.  `x` holds the pixel value in its low 8
-// bits; whatever lies above them is ignored, so callers pass a shifted word of packed pixels.
-// Counters are bytes, four to a word, in REVERSED order inside the word (value v of a fine
-// word sits in byte 3 - (v & 3), the coarse count of the values [64k, 64k+64) in byte 3 - k of
-// the register c64): the one-hot increment is then a single byte-align of a constant by the
-// low two bits of its operand.
-// A lane owns its words (word w of lane l at w * HM_LANES + l, so a lane only ever touches
-// bank l % 32) and nothing races; LDS add/sub instructions without a return value are used
-// because they are fire-and-forget, where a read-modify-write would serialise every update
-// behind an LDS round trip.  Those instructions are what bounds the kernel (about 16 cycles
-// per wave each), which is why the coarse level is four counters in a register and not a
-// second table in LDS.
+#define CM_LANES 64
+#define CM_STRIP 64
+// Counters are bytes, four to a word, in REVERSED order inside the word (value v of a fine word
+// sits in byte 3 - (v & 3), block m = v >> 4 in byte 3 - (m & 3) of block word m >> 2): the
+// one-hot increment is then a single byte-align of a constant by the low two bits of its
+// operand.  LDS add/sub instructions without a return value are fire-and-forget.
 template <bool ADD>
-__device__ __forceinline__ void hm_update(uint32_t *fine, uint32_t &c64, uint32_t x) {
-    const uint32_t f = __builtin_amdgcn_alignbyte(0u, 0x01000000u, x);       // 1 << 8 * (3 - (v & 3))
-    const uint32_t c = __builtin_amdgcn_alignbyte(0u, 0x01000000u, x >> 6);  // 1 << 8 * (3 - (v >> 6))
-    uint32_t *fw = fine + ((x >> 2) & 63u) * HM_LANES;                       // fine word v >> 2
+__device__ __forceinline__ void cm_update(uint32_t *fine, uint32_t *blocks, uint32_t v) {
+    const uint32_t f = __builtin_amdgcn_alignbyte(0u, 0x01000000u, v);       // 1 << 8 * (3 - (v & 3))
+    const uint32_t m = __builtin_amdgcn_alignbyte(0u, 0x01000000u, v >> 4);  // 1 << 8 * (3 - ((v >> 4) & 3))
+    uint32_t *fw = fine + (v >> 2) * CM_LANES;
+    uint32_t *bw = blocks + (v >> 6) * CM_LANES;
     if (ADD) {
         atomicAdd(fw, f);
-        c64 += c;
+        atomicAdd(bw, m);
     } else {
         atomicSub(fw, f);
-        c64 -= c;
+        atomicSub(bw, m);
     }
 }
 // the counters of a word in ascending order of value
 __device__ __forceinline__ uint32_t hm_ascending(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x00010203u); }
 // byte-wise helpers on four packed counters (totals never exceed 255, so no byte overflows)
 __device__ __forceinline__ uint32_t hm_prefix4(uint32_t x) {  // inclusive prefix sums, byte by byte
-    const uint32_t y = x + (x << 8);
-    return y + (y << 16);
+    // two shift-and-adds; written as asm because the compiler folds them into one multiplication by
+    // 0x01010101, and a 32-bit integer multiply issues at a quarter of the rate
+    uint32_t y, p;
+    asm("v_lshl_add_u32 %0, %1, 8, %1" : "=v"(y) : "v"(x));
+    asm("v_lshl_add_u32 %0, %1, 16, %1" : "=v"(p) : "v"(y));
+    return p;
 }
 __device__ __forceinline__ uint32_t hm_sum4(uint32_t x) { return __builtin_amdgcn_sad_u8(x, 0u, 0u); }
 // how many of the first three bytes of p are below need
@@ -395,13 +391,16 @@ __device__ __forceinline__ uint32_t hm_pick(uint32_t i, uint32_t x0, uint32_t x1
 }
 // 16 byte counters packed in w[0..3], ascending; `need` (>= 1) is how many more pixels, counted
 // from the first counter, the sought position lies: returns the index of the counter that
-// holds it.  The caller guarantees that the 16 counters together hold at least `need`.
-__device__ __forceinline__ uint32_t hm_find16(const uint32_t w[4], uint32_t need) {
+// holds it, and in `rest` how far into that counter it lies (need minus everything before the
+// counter).  The caller guarantees that the 16 counters together hold at least `need`.
+__device__ __forceinline__ uint32_t hm_find16(const uint32_t w[4], uint32_t need, uint32_t &rest) {
     const uint32_t t0 = hm_sum4(w[0]), t1 = t0 + hm_sum4(w[1]), t2 = t1 + hm_sum4(w[2]);  // totals through word 0, 1, 2
     const uint32_t k = (t0 < need ? 1u : 0u) + (t1 < need ? 1u : 0u) + (t2 < need ? 1u : 0u);
-    const uint32_t base = hm_pick(k, 0u, t0, t1, t2);
+    const uint32_t need1 = need - hm_pick(k, 0u, t0, t1, t2);
     const uint32_t p = hm_prefix4(hm_pick(k, w[0], w[1], w[2], w[3]));
-    return 4 * k + hm_below3(p, need - base);
+    const uint32_t i = hm_below3(p, need1);
+    rest = need1 - (((p << 8) >> (8 * i)) & 0xffu);  // minus the prefix through counter i - 1 (none for i == 0)
+    return 4 * k + i;
 }
 
 // One tap through the image's buffer descriptor: flat offsets outside [0, N) read 0.  The
@@ -414,135 +413,127 @@ __device__ __forceinline__ uint32_t hm_tap(__amdgpu_buffer_rsrc_t rsrc, int offs
 }
 
 template <int KW>
-__global__ __launch_bounds__(HM_LANES) void huang_median_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                                                int W, int H, long long in_stride, long long out_stride,
-                                                                int kH, int strips_x) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t hm_lds[];
-    uint32_t *fine = hm_lds + threadIdx.x;  // [64][LANES]
-    // the row that enters and the row that leaves, columns cx0-s .. cx0+LANES-1+s, loaded once
-    // per workgroup and step (double buffered: the next step's rows are fetched a step early)
-    uint8_t *rowbuf = reinterpret_cast<uint8_t *>(hm_lds + 64 * HM_LANES);  // [2 steps][2 rows][HM_ROWBUF]
-    const int N = W * H;  // the launcher keeps W * (H + 32) below 2^31
+__global__ __launch_bounds__(CM_LANES) void column_hist_median_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                                      int W, int H, long long in_stride, long long out_stride,
+                                                                      int kH, int strips_x) {
+    __shared__ uint32_t fine_all[64 * CM_LANES];   // [fine word][lane]
+    __shared__ uint32_t block_all[4 * CM_LANES];   // [block word][lane]
+    constexpr int s = (KW - 1) / 2;
+    constexpr int OUT_W = CM_LANES - 2 * s;  // columns a workgroup produces
+    const int lane = threadIdx.x;
+    uint32_t *fine = fine_all + lane, *blocks = block_all + lane;
+    const int N = W * H;  // the launcher keeps W * (H + CM_STRIP + 32) below 2^31
     const uint8_t *src = in + (long long)blockIdx.y * in_stride;
     uint8_t *dst = out + (long long)blockIdx.y * out_stride;
     // Taps come through a buffer descriptor over exactly the image: a flat offset outside
-    // [0, N) -- negative ones included, as unsigned -- reads 0 without a branch.
+    // [0, N) -- negative ones included, as unsigned -- reads 0 without a branch.  A column index
+    // below 0 or from W up is a pixel of the neighbouring row on the flat view (imageAnalysis.cu:657).
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
-    constexpr int kW = KW;
-    const int a = (kH - 1) / 2, s = (kW - 1) / 2;
+    const int a = (kH - 1) / 2;
     const int sy = blockIdx.x / strips_x, sx = blockIdx.x - sy * strips_x;
-    const int cx0 = sx * HM_LANES;
-    const int lane = threadIdx.x;
-    const int col = cx0 + lane;
-    const int y0 = sy * HM_STRIP;
-    const int y1 = (y0 + HM_STRIP < H) ? y0 + HM_STRIP : H;
-    const bool live = col < W && !(col < s || col > W - s);  // border columns produce zeros
+    const int col = sx * OUT_W - s + lane;  // this lane's column
+    const int y0 = sy * CM_STRIP;
+    const int y1 = (y0 + CM_STRIP < H) ? y0 + CM_STRIP : H;
+    const bool emits = lane >= s && lane < CM_LANES - s && col < W;  // this lane writes output pixels
+    const bool live = emits && !(col < s || col > W - s);            // border columns produce zeros
 #pragma unroll 8
-    for (int w = 0; w < 64; w++) fine[w * HM_LANES] = 0;  // the fine words
-    uint32_t c64 = 0;
-    const uint32_t need = (uint32_t)(kW * kH) / 2 + 1;  // position of sorted[taps / 2], counted from 1
-    // window of the strip's first row: a row of taps in flight at a time
-    if (live) {
-        int off = (y0 - a) * W + col - s;
-        for (int i = 0; i < kH; i++, off += W) {
-            uint32_t v[KW];
+    for (int w = 0; w < 64; w++) fine[w * CM_LANES] = 0;
 #pragma unroll
-            for (int j = 0; j < KW; j++) v[j] = hm_tap(rsrc, off + j, N);
-#pragma unroll
-            for (int j = 0; j < KW; j++) hm_update<true>(fine, c64, v[j]);
-        }
+    for (int w = 0; w < 4; w++) blocks[w * CM_LANES] = 0;
+    const uint32_t need = (uint32_t)(KW * kH) / 2 + 1;  // position of sorted[taps / 2], counted from 1
+    // the column's rows y0-a .. y0+a
+    {
+        int off = (y0 - a) * W + col;
+        for (int i = 0; i < kH; i++, off += W) cm_update<true>(fine, blocks, hm_tap(rsrc, off, N));
     }
-    // rows for the first slide (row y0-a leaves, row y0+1+a enters); the 2s halo columns to the
-    // right are fetched by the first 2s lanes (everyone else asks for offset N: out of range)
-    const bool has_extra = lane < 2 * s;
-    int top = (y0 - a) * W + (cx0 - s) + lane, bot = (y0 + 1 + a) * W + (cx0 - s) + lane;
-    uint32_t top0 = hm_tap(rsrc, top, N);
-    uint32_t bot0 = hm_tap(rsrc, bot, N);
-    uint32_t top1 = hm_tap(rsrc, has_extra ? top + HM_LANES : N, N);
-    uint32_t bot1 = hm_tap(rsrc, has_extra ? bot + HM_LANES : N, N);
-    uint8_t *q = dst + (long long)y0 * W + col;
-    for (int y = y0; y < y1; y++, q += W) {
-        uint8_t *rb = rowbuf + ((y - y0) & 1) * (2 * HM_ROWBUF);
-        rb[lane] = (uint8_t)top0;
-        rb[HM_ROWBUF + lane] = (uint8_t)bot0;
-        if (has_extra) {
-            rb[HM_LANES + lane] = (uint8_t)top1;
-            rb[HM_ROWBUF + HM_LANES + lane] = (uint8_t)bot1;
+    // All lanes are one wave and the LDS executes a wave's instructions in the order they were
+    // issued, so a lane sees its neighbours' updates without a barrier as long as the compiler
+    // keeps the order of the LDS accesses too: that is all cm_order() asks for.
+    auto cm_order = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // The window's counters: byte-wise sums of word w of the kW columns lane-s .. lane+s.  They are
+    // read as NP aligned pairs of columns (8-byte LDS reads move twice the data of 4-byte ones per
+    // cycle, and an aligned pair of columns never straddles a bank pair): the pairs starting at the
+    // even column at or below lane-s cover the window and one column more, the first of them when
+    // lane-s is odd, the last one otherwise; that one is masked out of the sum.
+    constexpr int NP = (KW + 2) / 2;  // KW odd: KW + 1 columns
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    auto window_words = [&](const uint32_t *base, u32x2_t (&raw)[4][NP]) {
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int k = 0; k < NP; k++) raw[w][k] = *reinterpret_cast<const u32x2_t *>(base + w * CM_LANES + 2 * k);
+    };
+    const int first_col = min(max(lane - s, 0), CM_LANES - KW);  // lanes that emit nothing read a valid window too
+    const int pair0 = first_col & ~1;
+    const uint32_t keep_first = (first_col & 1) ? 0u : 0xffffffffu, keep_last = ~keep_first;
+    auto sum_words = [&](const u32x2_t (&raw)[4][NP], uint32_t (&out)[4]) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t sum = (raw[w][0].x & keep_first) + (NP > 1 ? raw[w][0].y : (raw[w][0].y & keep_last));
+#pragma unroll
+            for (int k = 1; k < NP - 1; k++) sum += raw[w][k].x + raw[w][k].y;
+            if (NP > 1) sum += raw[w][NP - 1].x + (raw[w][NP - 1].y & keep_last);
+            out[w] = hm_ascending(sum);
         }
-        // fetch the rows of the next slide now, use them after the next barrier (past the
-        // strip's end they are never used, and past the image's end they read 0)
+    };
+    int top = (y0 - a) * W + col, bot = (y0 + a + 1) * W + col;  // the pixel that leaves / enters at the first slide
+    uint32_t t0 = hm_tap(rsrc, top, N), b0 = hm_tap(rsrc, bot, N);
+    uint8_t *q = dst + (long long)y0 * W + col;
+    // The loop is software-pipelined: the block counters of row y+1 are requested right behind the
+    // updates that make them, and travel while the fine counters of row y are searched.
+    // No branches inside the loop (the compiler would wait for every outstanding LDS access at
+    // each of them): lanes that emit nothing read a valid window all the same and drop the result,
+    // and the slide behind the strip's last row is done although nobody uses it.
+    const uint32_t *nb_blocks = block_all + pair0;
+    const uint32_t *nb_fine = fine_all + pair0;
+    u32x2_t braw[4][NP], fraw[4][NP];
+    cm_order();
+    window_words(nb_blocks, braw);
+    for (int y = y0; y < y1; y++, q += W) {
+        // the next slide's pixels are fetched now and used a step later
         top += W;
         bot += W;
-        top0 = hm_tap(rsrc, top, N);
-        bot0 = hm_tap(rsrc, bot, N);
-        top1 = hm_tap(rsrc, has_extra ? top + HM_LANES : N, N);
-        bot1 = hm_tap(rsrc, has_extra ? bot + HM_LANES : N, N);
-        uint32_t o = 0;
-        if (live && !(y < a || y > H - a)) {
-            // which quarter of the value range holds the sought position, from the register
-            const uint32_t p = hm_prefix4(hm_ascending(c64));
-            const uint32_t k = hm_below3(p, need);
-            const uint32_t need1 = need - (((p << 8) >> (8 * k)) & 0xffu);
-            // its 16 fine words, summed four at a time (byte-wise: totals stay below 256)
-            uint32_t fw[16];
-#pragma unroll
-            for (int w = 0; w < 16; w++) fw[w] = fine[(k * 16 + w) * HM_LANES];
-            const uint32_t T0 = hm_sum4(fw[0] + fw[1] + fw[2] + fw[3]), T1 = T0 + hm_sum4(fw[4] + fw[5] + fw[6] + fw[7]),
-                           T2 = T1 + hm_sum4(fw[8] + fw[9] + fw[10] + fw[11]);
-            const uint32_t g = (T0 < need1 ? 1u : 0u) + (T1 < need1 ? 1u : 0u) + (T2 < need1 ? 1u : 0u);
-            const uint32_t base = hm_pick(g, 0u, T0, T1, T2);
-            uint32_t sel[4];
-#pragma unroll
-            for (int w = 0; w < 4; w++) sel[w] = hm_ascending(hm_pick(g, fw[w], fw[4 + w], fw[8 + w], fw[12 + w]));
-            o = k * 64 + g * 16 + hm_find16(sel, need1 - base);
-        }
-        if (col < W) *q = (uint8_t)o;
-        __syncthreads();  // this step's rows are in rowbuf
-        if (live && y + 1 < y1) {
-            // the lane's kW pixels of either row: whole words read at once, then shifted so that
-            // byte 0 is the lane's own column (one LDS round trip per step, not one per pixel)
-            constexpr int NA = (KW + 3) / 4;
-            const uint32_t *rw = reinterpret_cast<const uint32_t *>(rb) + (lane >> 2);
-            uint32_t tw[NA + 1], bw[NA + 1];
-#pragma unroll
-            for (int w = 0; w <= NA; w++) {
-                tw[w] = rw[w];
-                bw[w] = rw[HM_ROWBUF / 4 + w];
-            }
-            const uint32_t sh = (uint32_t)lane & 3u;
-#pragma unroll
-            for (int qd = 0; qd < NA; qd++) {
-                const uint32_t t = __builtin_amdgcn_alignbyte(tw[qd + 1], tw[qd], sh);
-                const uint32_t b = __builtin_amdgcn_alignbyte(bw[qd + 1], bw[qd], sh);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (4 * qd + j < KW) {
-                        hm_update<false>(fine, c64, t >> (8 * j));
-                        hm_update<true>(fine, c64, b >> (8 * j));
-                    }
-                }
-            }
-        }
+        const uint32_t t1 = hm_tap(rsrc, top, N), b1 = hm_tap(rsrc, bot, N);
+        uint32_t mw[4], need2;
+        sum_words(braw, mw);
+        const uint32_t blk = hm_find16(mw, need, need2);
+        window_words(nb_fine + blk * (4 * CM_LANES), fraw);  // the 16 fine counters of that block
+        cm_order();
+        cm_update<false>(fine, blocks, t0);
+        cm_update<true>(fine, blocks, b0);
+        cm_order();
+        window_words(nb_blocks, braw);  // row y+1's block counters
+        uint32_t fw[4], need3;
+        sum_words(fraw, fw);
+        const uint32_t o = blk * 16 + hm_find16(fw, need2, need3);
+        const bool row_live = live && !(y < a || y > H - a);
+        if (emits) *q = (uint8_t)(row_live ? o : 0u);
+        t0 = t1;
+        b0 = b1;
     }
 }
 
-static int launch_huang_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
-                               long long out_stride, int kW, int kH, hipStream_t s) {
-    if (kW * kH > 255 || (long long)W * ((long long)H + 32) >= (1LL << 31)) return IAK_E_UNSUPPORTED;
-    const int strips_x = (W + HM_LANES - 1) / HM_LANES, strips_y = (H + HM_STRIP - 1) / HM_STRIP;
-    const size_t lds = sizeof(uint32_t) * 64 * HM_LANES + 4 * HM_ROWBUF;
+static int launch_column_hist_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
+                                     long long out_stride, int kW, int kH, hipStream_t s) {
+    if (kW * kH > 255 || kW > 25 || (long long)W * ((long long)H + CM_STRIP + 32) >= (1LL << 31)) return IAK_E_UNSUPPORTED;
+    const int out_w = CM_LANES - (kW - 1);
+    const int strips_x = (W + out_w - 1) / out_w, strips_y = (H + CM_STRIP - 1) / CM_STRIP;
     const dim3 grid((unsigned)(strips_x * strips_y), B);
-#define HM_CASE(K)                                                                                                     \
-    case K:                                                                                                            \
-        hipLaunchKernelGGL(huang_median_kernel<K>, grid, dim3(HM_LANES), lds, s, in, out, W, H, in_stride, out_stride, kH, \
-                           strips_x);                                                                                  \
+#define CM_CASE(K)                                                                                                       \
+    case K:                                                                                                              \
+        hipLaunchKernelGGL(column_hist_median_kernel<K>, grid, dim3(CM_LANES), 0, s, in, out, W, H, in_stride, out_stride, kH, \
+                           strips_x);                                                                                    \
         break;
     switch (kW) {
-        HM_CASE(1) HM_CASE(3) HM_CASE(5) HM_CASE(7) HM_CASE(9) HM_CASE(11) HM_CASE(13) HM_CASE(15) HM_CASE(17)
-        HM_CASE(19) HM_CASE(21) HM_CASE(23) HM_CASE(25)
+        CM_CASE(1) CM_CASE(3) CM_CASE(5) CM_CASE(7) CM_CASE(9) CM_CASE(11) CM_CASE(13) CM_CASE(15) CM_CASE(17)
+        CM_CASE(19) CM_CASE(21) CM_CASE(23) CM_CASE(25)
     default: return IAK_E_UNSUPPORTED;
     }
-#undef HM_CASE
+#undef CM_CASE
     IAK_LAUNCH_CHECK();
     return 0;
 }

@@ -204,7 +204,7 @@ int iak_features_static(const uint8_t *img, int W, int H, int B, long long strid
  * per-class feature sums, C x 7 sums of squares, as doubles (DEVICE double[256 + 15 * C], fully
  * overwritten).  features: DEVICE float[B][7] as iak_features / IAK_OP_FEATURES write them;
  * labels: DEVICE int32[B], class of image b in [0, C) (test/test.cu:541-550 keeps the same rows
- * and labels on the host); other labels are not counted.  Sums run over the images in order:
+ * and labels on the host); other labels are not counted.  Every sum is formed in a fixed order:
  * results do not depend on scheduling, and every integer stays exact (< 2^53). */
 int iak_dataset_sums(const unsigned long long *hist_sum, const float *features, const int32_t *labels, int B,
                      int C, double *packed, void *stream);
