@@ -9,6 +9,18 @@
 // condition for all 256 pixel values before this path is taken; anything else goes through the
 // tap-by-tap kernel.
 //
+// Weights such as fl(1/121) miss that condition for a few pixel values only: 121 * fl(1/121) lies
+// one float step below 1, so that tap adds floor(p) = 0 to a sum of 0 and, the float sum then
+// rounding up, 1 to any sum >= 1.  When every pixel value is either exact as above or "special" in
+// exactly that way (floor(p) onto an empty sum, floor(p) + 1 onto any other; the host tries every
+// pixel value against every possible sum), the filter is still an order-free box sum plus a
+// count: a special tap earns its extra 1 iff an earlier tap of the window, in the reference's
+// row-major tap order, has contributed at least 1.  Per window that is
+//   sum f + (#special - #special before the first tap with f >= 1),   or sum f if no tap has f >= 1,
+// (a special tap that is itself the first one with f >= 1 counts as "before": it lands on an
+// empty sum), with #special and #(f >= 1) box sums of their own (they ride in spare bits of the same
+// elements) and the walk to the first contributing tap only where a window holds both kinds.
+//
 // A workgroup of 256 lanes makes a 64 x 64 tile of outputs: (A) the (64+kH-1) x (64+kW-1) input
 // tile, on the flat view of the image (taps outside it read 0), is staged in LDS as 16-bit
 // floor(pixel * w); (B) sliding vertical sums, two columns per lane as one packed word;
@@ -46,23 +58,48 @@ inline bool box_sum_exact(float w, int taps) {
     return true;
 }
 
-template <bool AVG>
-__global__ __launch_bounds__(256) void box_sum_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W, int H,
-                                                      long long in_stride, long long out_stride, int kW, int kH, float w,
-                                                      int divisor, int tiles_x) {
-    __shared__ __attribute__((aligned(16))) uint16_t t1[BX_IN * BX_PITCH];  // floor(pixel * w)
-    __shared__ __attribute__((aligned(16))) uint16_t t2[BX_T * BX_PITCH];   // vertical sums
-    const int N = W * H;  // the launcher keeps W * (H + 32) below 2^31
-    const uint8_t *src = in + (long long)blockIdx.y * in_stride;
-    uint8_t *dst = out + (long long)blockIdx.y * out_stride;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
-    const int a = (kH - 1) / 2, s = (kW - 1) / 2;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int x0 = tx * BX_T, y0 = ty * BX_T;
-    const int IW = BX_T + kW - 1, IH = BX_T + kH - 1;
+// How the box path applies to weight w over a kW x kH window: BOX_NO, BOX_PLAIN, or BOX_SPECIAL
+// with the (at most BOX_MAX_SPECIAL) pixel values that add one more onto a non-empty sum.  The special form keeps three counts in one 16-bit element (see box_special_kernel), which
+// bounds floor(255 * w) by 3 and the window by 15 x 15.
+enum { BOX_NO = 0, BOX_PLAIN = 1, BOX_SPECIAL = 2 };
+#define BOX_MAX_SPECIAL 4
+struct BoxSpecial {
+    uint32_t value[BOX_MAX_SPECIAL];  // unused entries hold 256 (no pixel has that value)
+};
+inline int box_classify(float w, int kW, int kH, BoxSpecial *sp) {
+    const int taps = kW * kH;
+    if (box_sum_exact(w, taps)) return BOX_PLAIN;
+    if (!(w > 0.0f) || !(255.0f * w < 4.0f) || kW > 15 || kH > 15) return BOX_NO;
+    for (int i = 0; i < BOX_MAX_SPECIAL; i++) sp->value[i] = 256;
+    const int smax = 3 * taps + taps;  // above every running sum
+    int any = 0;
+    for (int px = 0; px < 256; px++) {
+        const float p = (float)px * w;
+        const int fl = (int)p;
+        int up_from = -1;  // first running sum at which the tap gives floor + 1
+        bool ok = true;
+        for (int sum = 0; sum <= smax && ok; sum++) {
+            const int d = (int)((float)sum + p) - (sum + fl);
+            if (d == 0) ok = up_from < 0;            // exact here: must not have deviated at a smaller sum
+            else if (d == 1) { if (up_from < 0) up_from = sum; }
+            else ok = false;
+        }
+        if (!ok || (up_from >= 0 && up_from != 1)) return BOX_NO;
+        if (up_from == 1) {
+            if (any == BOX_MAX_SPECIAL) return BOX_NO;
+            sp->value[any++] = (uint32_t)px;
+        }
+    }
+    return any ? BOX_SPECIAL : BOX_NO;
+}
+
+// (A) of both kernels: a wave per row, lanes along it (two passes cover up to 88 columns); eight
+// rows' loads are issued before the first is used, so that their latencies overlap.
+// With `lut` (256 entries in LDS, ready before the call) the element is lut[pixel] instead.
+template <bool SPECIAL>
+__device__ __forceinline__ void box_stage_tile(uint16_t *t1, __amdgpu_buffer_rsrc_t rsrc, int N, int W, int x0, int y0, int a,
+                                               int s, int IW, int IH, float w, const uint16_t *lut) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // (A) a wave per row, lanes along it (two passes cover up to 88 columns); eight rows' loads are
-    // issued before the first is used, so that their latencies overlap
     for (int rb = wave; rb < IH; rb += 32) {
         uint32_t v[8][2];
 #pragma unroll
@@ -85,10 +122,28 @@ __global__ __launch_bounds__(256) void box_sum_kernel(const uint8_t *__restrict_
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const int c = lane + 64 * k;
-                if (r < IH && c < IW) t1[r * BX_PITCH + c] = (uint16_t)(uint32_t)((float)v[u][k] * w);
+                if (r < IH && c < IW)
+                    t1[r * BX_PITCH + c] = SPECIAL ? lut[v[u][k]] : (uint16_t)(uint32_t)((float)v[u][k] * w);
             }
         }
     }
+}
+
+template <bool AVG>
+__global__ __launch_bounds__(256) void box_sum_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W, int H,
+                                                      long long in_stride, long long out_stride, int kW, int kH, float w,
+                                                      int divisor, int tiles_x) {
+    __shared__ __attribute__((aligned(16))) uint16_t t1[BX_IN * BX_PITCH];  // floor(pixel * w)
+    __shared__ __attribute__((aligned(16))) uint16_t t2[BX_T * BX_PITCH];   // vertical sums
+    const int N = W * H;  // the launcher keeps W * (H + 32) below 2^31
+    const uint8_t *src = in + (long long)blockIdx.y * in_stride;
+    uint8_t *dst = out + (long long)blockIdx.y * out_stride;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
+    const int a = (kH - 1) / 2, s = (kW - 1) / 2;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * BX_T, y0 = ty * BX_T;
+    const int IW = BX_T + kW - 1, IH = BX_T + kH - 1;
+    box_stage_tile<false>(t1, rsrc, N, W, x0, y0, a, s, IW, IH, w, nullptr);
     __syncthreads();
     // (B) column pairs x four segments of 16 output rows: sliding sums of kH rows.  Two 16-bit
     // sums travel in one word; a carry from the low half into the high one during an add is
@@ -143,21 +198,141 @@ __global__ __launch_bounds__(256) void box_sum_kernel(const uint8_t *__restrict_
     }
 }
 
+// The special form, rows first.  Per window the specials that earn nothing are those in front of
+// (and including) the first contributing tap in row-major order: all specials of the window rows
+// above the first row that holds a contributing tap, plus, in that row, the specials up to that tap.
+// (A) an element of the staged tile is floor(pixel * w) (2 bits) | special << 6 | contributing << 10,
+// from a 256-entry table the workgroup makes first.  (B) per input row: sliding sums of kW (<= 15)
+// columns -- floor sum, #special and #contributing stay apart in 6 + 4 + 4 bits -- and, by a
+// right-to-left pass, for every column the number G of specials from it up to and including the
+// next contributing tap (only used where that tap lies inside the window); stored as one word
+// per (row, column): floor sum | #special << 10 | #contributing << 18 | G << 26.  (C) one lane per
+// output column and 16-row segment, from the bottom row up: sliding sums of kH (<= 15) rows of those
+// words (10 + 8 + 8 bits hold the window's counts; what the G fields add up to above them drops
+// out of the top), and one running number, "specials that earn nothing if the window started at
+// this row": restarted from G at a row with a contributing tap, grown by the row's specials
+// otherwise.  No branches on the pixel data.
+#define BXS_PITCH (BX_T + 1)
+// KW is a template parameter so that the row passes unroll and their LDS reads travel together.
+template <bool AVG, int KW>
+__global__ __launch_bounds__(256) void box_special_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
+                                                          int H, long long in_stride, long long out_stride, int kH,
+                                                          float w, int divisor, int tiles_x, BoxSpecial sp) {
+    constexpr int kW = KW;
+    __shared__ __attribute__((aligned(16))) uint16_t t1[BX_IN * BX_PITCH];  // per pixel: floor | special | contributing
+    __shared__ uint32_t t2[(BX_T + 14) * BXS_PITCH];                        // per input row and column: see above
+    __shared__ uint16_t lut[256];
+    {
+        const uint32_t px = threadIdx.x;
+        const uint32_t f = (uint32_t)((float)px * w);
+        const uint32_t special = (px == sp.value[0] || px == sp.value[1] || px == sp.value[2] || px == sp.value[3]) ? 1u : 0u;
+        lut[px] = (uint16_t)(f | (special << 6) | ((f >= 1u ? 1u : 0u) << 10));
+    }
+    __syncthreads();
+    const int N = W * H;  // the launcher keeps W * (H + 32) below 2^31
+    const uint8_t *src = in + (long long)blockIdx.y * in_stride;
+    uint8_t *dst = out + (long long)blockIdx.y * out_stride;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
+    const int a = (kH - 1) / 2, s = (kW - 1) / 2;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * BX_T, y0 = ty * BX_T;
+    const int IW = BX_T + kW - 1, IH = BX_T + kH - 1;
+    box_stage_tile<true>(t1, rsrc, N, W, x0, y0, a, s, IW, IH, w, lut);
+    __syncthreads();
+    // (B) IH rows x 8 chunks of 8 outputs
+    for (int task = threadIdx.x; task < IH * 8; task += 256) {
+        const int r = task >> 3, c0 = (task & 7) << 3;
+        const uint16_t *rowp = t1 + r * BX_PITCH + c0;
+        uint32_t el[8 + KW - 1];  // the chunk's 8 windows
+#pragma unroll
+        for (int c = 0; c < 8 + KW - 1; c++) el[c] = rowp[c];
+        uint32_t g8[8], g = 0;
+#pragma unroll
+        for (int c = 7 + KW - 1; c >= 0; c--) {
+            const uint32_t special = (el[c] >> 6) & 1u;
+            g = (el[c] & 0x400u) ? special : g + special;
+            if (c < 8) g8[c] = g;
+        }
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < KW; j++) acc += el[j];
+        uint32_t *d2 = t2 + r * BXS_PITCH + c0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (i) acc += el[i + KW - 1] - el[i - 1];
+            d2[i] = (acc & 0x3fu) | ((acc & 0x3c0u) << 4) | ((acc & 0x3c00u) << 8) | (g8[i] << 26);
+        }
+    }
+    __syncthreads();
+    // (C) 64 columns x 4 segments of 16 rows, bottom row first
+    const int x = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int col = x0 + x;
+    if (col >= W) return;
+    const uint32_t *colp = t2 + (seg * 16) * BXS_PITCH + x;
+    uint32_t acc = 0, before = 0;
+    auto step = [&](uint32_t e) {  // one row further up
+        acc += e;
+        before = (e & 0x03fc0000u) ? ((e >> 26) & 0xfu) : before + ((e >> 10) & 0xffu);
+    };
+    // the window of the segment's last row, but for its top row, which the loop below adds
+#pragma unroll 4
+    for (int r = 15 + kH - 1; r > 15; r--) step(colp[r * BXS_PITCH]);
+#pragma unroll
+    for (int i = 15; i >= 0; i--) {
+        step(colp[i * BXS_PITCH]);
+        if (i < 15) acc -= colp[(i + kH) * BXS_PITCH];
+        const int row = y0 + seg * 16 + i;
+        if (row >= H) continue;
+        uint32_t sum = acc & 0x3ffu;
+        const uint32_t n_special = (acc >> 10) & 0xffu, n_big = (acc >> 18) & 0xffu;
+        if (n_big != 0) sum += n_special - before;  // with a contributing tap in the window, `before` counts inside it
+        uint32_t r8;
+        if (AVG) r8 = (sum / (uint32_t)divisor) & 0xffu;  // imageAnalysis.cu:487: no clamp, wraps
+        else r8 = sum > 255u ? 255u : sum;
+        const bool border = row < a || row > H - a || col < s || col > W - s;
+        dst[(long long)row * W + col] = (uint8_t)(border ? 0u : r8);
+    }
+}
+
 // kW, kH: the odd window actually visited (at most 25 x 25); w its one weight; divisor: for the
 // average filter.  IAK_E_UNSUPPORTED when the path does not apply.
 static int launch_box_sum(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
                           int kW, int kH, float w, int divisor, bool avg, hipStream_t s) {
     if (kW > 25 || kH > 25 || kW < 1 || kH < 1 || (long long)W * ((long long)H + 32) >= (1LL << 31)) return IAK_E_UNSUPPORTED;
     if (avg && divisor <= 0) return IAK_E_UNSUPPORTED;
-    if (!box_sum_exact(w, kW * kH)) return IAK_E_UNSUPPORTED;
+    // the classification tries every pixel value against every sum: remembered for the last weight seen
+    struct Memo { float w; int kW, kH, kind; BoxSpecial sp; };
+    static thread_local Memo memo = {0.0f, 0, 0, BOX_NO, {}};
+    if (!(memo.w == w && memo.kW == kW && memo.kH == kH)) {
+        Memo m{w, kW, kH, BOX_NO, {}};
+        m.kind = box_classify(w, kW, kH, &m.sp);
+        memo = m;
+    }
+    if (memo.kind == BOX_NO) return IAK_E_UNSUPPORTED;
     const int tiles_x = (W + BX_T - 1) / BX_T, tiles_y = (H + BX_T - 1) / BX_T;
     const dim3 grid((unsigned)(tiles_x * tiles_y), B);
-    if (avg)
+    if (memo.kind == BOX_SPECIAL) {
+#define BXS_CASE(K)                                                                                                       \
+    case K:                                                                                                               \
+        if (avg)                                                                                                          \
+            hipLaunchKernelGGL((box_special_kernel<true, K>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, kH, w, \
+                               divisor, tiles_x, memo.sp);                                                                \
+        else                                                                                                              \
+            hipLaunchKernelGGL((box_special_kernel<false, K>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, kH, \
+                               w, divisor, tiles_x, memo.sp);                                                             \
+        break;
+        switch (kW) {
+            BXS_CASE(1) BXS_CASE(3) BXS_CASE(5) BXS_CASE(7) BXS_CASE(9) BXS_CASE(11) BXS_CASE(13) BXS_CASE(15)
+        default: return IAK_E_UNSUPPORTED;
+        }
+#undef BXS_CASE
+    } else if (avg) {
         hipLaunchKernelGGL(box_sum_kernel<true>, grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, kW, kH, w, divisor,
                            tiles_x);
-    else
+    } else {
         hipLaunchKernelGGL(box_sum_kernel<false>, grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, kW, kH, w, divisor,
                            tiles_x);
+    }
     IAK_LAUNCH_CHECK();
     return 0;
 }

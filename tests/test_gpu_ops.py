@@ -280,6 +280,38 @@ def test_box_filters(ops, w, kW, kH, W, H, kind):
     each(lambda x: ops.averageFilter(x, k, kW, kH), lambda x: O.average(x, k, kW, kH), imgs)
 
 
+@pytest.mark.parametrize("kW,kH,w", [(11, 11, 1.0 / 121), (7, 7, 1.0 / 49), (13, 13, 1.0 / 169), (11, 5, 1.0 / 55),
+                                       (3, 15, 1.0 / 45), (25, 9, 1.0 / 121), (11, 11, 1.0 / 242), (11, 11, 3.0 / 242)])
+@pytest.mark.parametrize("W,H", [(200, 70), (64, 64), (131, 45), (9, 40)])
+def test_box_filters_whose_taps_depend_on_the_running_sum(ops, kW, kH, w, W, H):
+    """Weights like fl(1/121): 121 * w lies one float step below 1, so that tap adds 0 to an empty
+    running sum and 1 to any other (imageAnalysis.cu:517-524 truncates after every tap) -- the
+    result depends on the order of the taps.  Images made of the critical pixel values and their
+    neighbours, in dark / bright arrangements that put the first contributing tap anywhere in a
+    window, against the oracle's tap-by-tap loop."""
+    rs = np.random.default_rng(kW * 1000 + kH * 10 + W)
+    q = int(round(1.0 / w)) if w < 0.5 else 1
+    critical = sorted({v for m in (1, 2, 3) for v in (m * q - 1, m * q, m * q + 1) if 0 <= v <= 255} | {0, 255})
+    imgs = []
+    # (1) only critical values; (2) mostly dark with a few of them; (3) dark top half, bright bottom; (4) bright left columns
+    a = rs.choice(critical, size=(H, W)).astype(np.uint8)
+    imgs.append(a)
+    b = rs.integers(0, min(q, 255), size=(H, W)).astype(np.uint8)
+    m = rs.random((H, W)) < 0.03
+    b[m] = rs.choice(critical, size=int(m.sum()))
+    imgs.append(b)
+    c = b.copy()
+    c[H // 2:] = rs.choice(critical + [200, 201], size=(H - H // 2, W))
+    imgs.append(c)
+    d = b.copy()
+    d[:, : max(1, W // 3)] = rs.choice(critical, size=(H, max(1, W // 3)))
+    imgs.append(d)
+    imgs = np.stack(imgs)
+    k = np.full(kW * kH, w, np.float32)
+    each(lambda x: ops.linearFilter(x, k, kW, kH), lambda x: O.linear(x, k, kW, kH), imgs)
+    each(lambda x: ops.averageFilter(x, k, kW, kH), lambda x: O.average(x, k, kW, kH), imgs)
+
+
 @pytest.mark.parametrize("kW,kH", [(5, 5), (7, 7), (15, 15), (3, 9), (9, 3), (1, 5), (5, 1), (15, 17)])
 @pytest.mark.parametrize("W,H,kind", [(200, 70, "C"), (131, 150, "U"), (64, 33, "K"), (300, 20, "C"), (5, 9, "U")])
 def test_median_sliding_histogram(ops, kW, kH, W, H, kind):
