@@ -128,7 +128,7 @@ KERNEL_OF_GROUP = {
 KERNEL_OF_GROUP_BY_WORKLOAD = {
     "P-A/config": {"equalize+gauss+salt_pepper+linear": "iak::chain_stencil8_flat_kernel<iak::Lin8Pk16<false> >",
                    "linear": "iak::stencil8_kernel<iak::Lin8Pk16<false>, 8, false, false>"},
-    "P-B": {"linear": "iak::box_special_kernel<false, 11>", "median": "iak::column_hist_median_kernel<7>"},
+    "P-B": {"linear": "iak::box_special_kernel<false, 11>", "median": "iak::column_hist_median_kernel<7, 2>"},
     "P-C": {"otsu": "iak::chain_apply_kernel<false>", "otsu+sobel": "iak::binary_table_stencil_kernel",
             "dilate+erode+hist": "iak::morph_chain_kernel<2, 2, false>", "features": "iak::perimeter_bits_kernel"},
 }

@@ -353,11 +353,13 @@ static int launch_tiled_morph(const uint8_t *in, uint8_t *out, int W, int H, int
 // sits in byte 3 - (v & 3), block m = v >> 4 in byte 3 - (m & 3) of block word m >> 2): the
 // one-hot increment is then a single byte-align of a constant by the low two bits of its
 // operand.  LDS add/sub instructions without a return value are fire-and-forget.
-template <bool ADD>
+// NIB: the fine counters are 4 bits wide (a column holds at most 15 pixels), eight to a word in
+// natural order: half the table, twice the waves per CU.
+template <bool ADD, bool NIB>
 __device__ __forceinline__ void cm_update(uint32_t *fine, uint32_t *blocks, uint32_t v) {
-    const uint32_t f = __builtin_amdgcn_alignbyte(0u, 0x01000000u, v);       // 1 << 8 * (3 - (v & 3))
+    const uint32_t f = NIB ? (1u << ((v & 7u) << 2)) : __builtin_amdgcn_alignbyte(0u, 0x01000000u, v);  // 1 << 8 * (3 - (v & 3))
     const uint32_t m = __builtin_amdgcn_alignbyte(0u, 0x01000000u, v >> 4);  // 1 << 8 * (3 - ((v >> 4) & 3))
-    uint32_t *fw = fine + (v >> 2) * CM_LANES;
+    uint32_t *fw = fine + (NIB ? (v >> 3) : (v >> 2)) * CM_LANES;
     uint32_t *bw = blocks + (v >> 6) * CM_LANES;
     if (ADD) {
         atomicAdd(fw, f);
@@ -394,13 +396,20 @@ __device__ __forceinline__ uint32_t hm_pick(uint32_t i, uint32_t x0, uint32_t x1
 // holds it, and in `rest` how far into that counter it lies (need minus everything before the
 // counter).  The caller guarantees that the 16 counters together hold at least `need`.
 __device__ __forceinline__ uint32_t hm_find16(const uint32_t w[4], uint32_t need, uint32_t &rest) {
-    const uint32_t t0 = hm_sum4(w[0]), t1 = t0 + hm_sum4(w[1]), t2 = t1 + hm_sum4(w[2]);  // totals through word 0, 1, 2
-    const uint32_t k = (t0 < need ? 1u : 0u) + (t1 < need ? 1u : 0u) + (t2 < need ? 1u : 0u);
-    const uint32_t need1 = need - hm_pick(k, 0u, t0, t1, t2);
-    const uint32_t p = hm_prefix4(hm_pick(k, w[0], w[1], w[2], w[3]));
-    const uint32_t i = hm_below3(p, need1);
-    rest = need1 - (((p << 8) >> (8 * i)) & 0xffu);  // minus the prefix through counter i - 1 (none for i == 0)
-    return 4 * k + i;
+    // totals through word 0, 1, 2 (the byte-sum instruction adds onto its third operand)
+    const uint32_t t0 = __builtin_amdgcn_sad_u8(w[0], 0u, 0u), t1 = __builtin_amdgcn_sad_u8(w[1], 0u, t0),
+                   t2 = __builtin_amdgcn_sad_u8(w[2], 0u, t1);
+    // the totals ascend, so the three comparisons select directly (no index arithmetic in between)
+    const bool c0 = t0 < need, c1 = t1 < need, c2 = t2 < need;
+    const uint32_t word = c2 ? w[3] : (c1 ? w[2] : (c0 ? w[1] : w[0]));
+    const uint32_t base = c2 ? t2 : (c1 ? t1 : (c0 ? t0 : 0u));
+    const uint32_t k4 = c2 ? 12u : (c1 ? 8u : (c0 ? 4u : 0u));
+    const uint32_t need1 = need - base;
+    const uint32_t p = hm_prefix4(word);
+    const uint32_t p0 = p & 0xffu, p1 = (p >> 8) & 0xffu, p2 = (p >> 16) & 0xffu;
+    const bool d0 = p0 < need1, d1 = p1 < need1, d2 = p2 < need1;
+    rest = need1 - (d2 ? p2 : (d1 ? p1 : (d0 ? p0 : 0u)));  // minus the prefix through the counter before
+    return k4 + (d2 ? 3u : (d1 ? 2u : (d0 ? 1u : 0u)));
 }
 
 // One tap through the image's buffer descriptor: flat offsets outside [0, N) read 0.  The
@@ -412,11 +421,15 @@ __device__ __forceinline__ uint32_t hm_tap(__amdgpu_buffer_rsrc_t rsrc, int offs
     return __builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)o, 0, 0);
 }
 
-template <int KW>
+// MODE 0: byte counters; 1: 4-bit fine counters (kH <= 15); 2: the same with kH <= 7, where the
+// counters of two columns can be added before the nibbles are taken apart (7 + 7 < 16).
+template <int KW, int MODE>
 __global__ __launch_bounds__(CM_LANES) void column_hist_median_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                                       int W, int H, long long in_stride, long long out_stride,
                                                                       int kH, int strips_x) {
-    __shared__ uint32_t fine_all[64 * CM_LANES];   // [fine word][lane]
+    constexpr bool NIB = MODE != 0;
+    constexpr int FINE_WORDS = NIB ? 32 : 64;
+    __shared__ uint32_t fine_all[FINE_WORDS * CM_LANES];   // [fine word][lane]
     __shared__ uint32_t block_all[4 * CM_LANES];   // [block word][lane]
     constexpr int s = (KW - 1) / 2;
     constexpr int OUT_W = CM_LANES - 2 * s;  // columns a workgroup produces
@@ -437,14 +450,14 @@ __global__ __launch_bounds__(CM_LANES) void column_hist_median_kernel(const uint
     const bool emits = lane >= s && lane < CM_LANES - s && col < W;  // this lane writes output pixels
     const bool live = emits && !(col < s || col > W - s);            // border columns produce zeros
 #pragma unroll 8
-    for (int w = 0; w < 64; w++) fine[w * CM_LANES] = 0;
+    for (int w = 0; w < FINE_WORDS; w++) fine[w * CM_LANES] = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) blocks[w * CM_LANES] = 0;
     const uint32_t need = (uint32_t)(KW * kH) / 2 + 1;  // position of sorted[taps / 2], counted from 1
     // the column's rows y0-a .. y0+a
     {
         int off = (y0 - a) * W + col;
-        for (int i = 0; i < kH; i++, off += W) cm_update<true>(fine, blocks, hm_tap(rsrc, off, N));
+        for (int i = 0; i < kH; i++, off += W) cm_update<true, NIB>(fine, blocks, hm_tap(rsrc, off, N));
     }
     // All lanes are one wave and the LDS executes a wave's instructions in the order they were
     // issued, so a lane sees its neighbours' updates without a barrier as long as the compiler
@@ -470,6 +483,36 @@ __global__ __launch_bounds__(CM_LANES) void column_hist_median_kernel(const uint
     const int first_col = min(max(lane - s, 0), CM_LANES - KW);  // lanes that emit nothing read a valid window too
     const int pair0 = first_col & ~1;
     const uint32_t keep_first = (first_col & 1) ? 0u : 0xffffffffu, keep_last = ~keep_first;
+    auto window_words2 = [&](const uint32_t *base, u32x2_t (&raw)[4][NP]) {  // two word rows only
+#pragma unroll
+        for (int w = 0; w < 2; w++)
+#pragma unroll
+            for (int k = 0; k < NP; k++) raw[w][k] = *reinterpret_cast<const u32x2_t *>(base + w * CM_LANES + 2 * k);
+    };
+    // nibble counters: even and odd nibbles are added up apart, as bytes, and interleaved again --
+    // out[0..3] = the counters of values 0-3, 4-7, 8-11, 12-15 of the block, ascending
+    auto sum_nibble_words = [&](const u32x2_t (&raw)[4][NP], uint32_t (&out)[4]) {
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+            uint32_t even = 0, odd = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                uint32_t x = raw[w][k].x, y = raw[w][k].y;
+                if (k == 0) x &= keep_first;
+                if (k == NP - 1) y &= keep_last;
+                if (MODE == 2) {
+                    const uint32_t xy = x + y;
+                    even += xy & 0x0f0f0f0fu;
+                    odd += (xy >> 4) & 0x0f0f0f0fu;
+                } else {
+                    even += (x & 0x0f0f0f0fu) + (y & 0x0f0f0f0fu);
+                    odd += ((x >> 4) & 0x0f0f0f0fu) + ((y >> 4) & 0x0f0f0f0fu);
+                }
+            }
+            out[2 * w] = __builtin_amdgcn_perm(odd, even, 0x05010400u);      // values 0, 1, 2, 3
+            out[2 * w + 1] = __builtin_amdgcn_perm(odd, even, 0x07030602u);  // values 4, 5, 6, 7
+        }
+    };
     auto sum_words = [&](const u32x2_t (&raw)[4][NP], uint32_t (&out)[4]) {
 #pragma unroll
         for (int w = 0; w < 4; w++) {
@@ -501,14 +544,17 @@ __global__ __launch_bounds__(CM_LANES) void column_hist_median_kernel(const uint
         uint32_t mw[4], need2;
         sum_words(braw, mw);
         const uint32_t blk = hm_find16(mw, need, need2);
-        window_words(nb_fine + blk * (4 * CM_LANES), fraw);  // the 16 fine counters of that block
+        // the 16 fine counters of that block: four words of bytes, or two of nibbles
+        if (NIB) window_words2(nb_fine + blk * (2 * CM_LANES), fraw);
+        else window_words(nb_fine + blk * (4 * CM_LANES), fraw);
         cm_order();
-        cm_update<false>(fine, blocks, t0);
-        cm_update<true>(fine, blocks, b0);
+        cm_update<false, NIB>(fine, blocks, t0);
+        cm_update<true, NIB>(fine, blocks, b0);
         cm_order();
         window_words(nb_blocks, braw);  // row y+1's block counters
         uint32_t fw[4], need3;
-        sum_words(fraw, fw);
+        if (NIB) sum_nibble_words(fraw, fw);
+        else sum_words(fraw, fw);
         const uint32_t o = blk * 16 + hm_find16(fw, need2, need3);
         const bool row_live = live && !(y < a || y > H - a);
         if (emits) *q = (uint8_t)(row_live ? o : 0u);
@@ -520,13 +566,21 @@ __global__ __launch_bounds__(CM_LANES) void column_hist_median_kernel(const uint
 static int launch_column_hist_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
                                      long long out_stride, int kW, int kH, hipStream_t s) {
     if (kW * kH > 255 || kW > 25 || (long long)W * ((long long)H + CM_STRIP + 32) >= (1LL << 31)) return IAK_E_UNSUPPORTED;
+    const int mode = kH <= 7 ? 2 : (kH <= 15 ? 1 : 0);  // a column's counters fit four bits up to 15 rows
     const int out_w = CM_LANES - (kW - 1);
     const int strips_x = (W + out_w - 1) / out_w, strips_y = (H + CM_STRIP - 1) / CM_STRIP;
     const dim3 grid((unsigned)(strips_x * strips_y), B);
 #define CM_CASE(K)                                                                                                       \
     case K:                                                                                                              \
-        hipLaunchKernelGGL(column_hist_median_kernel<K>, grid, dim3(CM_LANES), 0, s, in, out, W, H, in_stride, out_stride, kH, \
-                           strips_x);                                                                                    \
+        if (mode == 2)                                                                                                   \
+            hipLaunchKernelGGL((column_hist_median_kernel<K, 2>), grid, dim3(CM_LANES), 0, s, in, out, W, H, in_stride,         \
+                               out_stride, kH, strips_x);                                                                \
+        else if (mode == 1)                                                                                              \
+            hipLaunchKernelGGL((column_hist_median_kernel<K, 1>), grid, dim3(CM_LANES), 0, s, in, out, W, H, in_stride,         \
+                               out_stride, kH, strips_x);                                                                \
+        else                                                                                                             \
+            hipLaunchKernelGGL((column_hist_median_kernel<K, 0>), grid, dim3(CM_LANES), 0, s, in, out, W, H, in_stride,         \
+                               out_stride, kH, strips_x);                                                                \
         break;
     switch (kW) {
         CM_CASE(1) CM_CASE(3) CM_CASE(5) CM_CASE(7) CM_CASE(9) CM_CASE(11) CM_CASE(13) CM_CASE(15) CM_CASE(17)
