@@ -39,10 +39,11 @@ __device__ __forceinline__ void hist_flush(const uint32_t *sh, uint32_t *hist_im
 }
 
 // A workgroup's 32 KiB table and its 256-atomic merge are amortised over the pixels it
-// streams: give each at least ~64K pixels, and keep the whole launch near 2-4K workgroups.
+// streams: give each (1024 lanes) at least ~256K pixels, and keep the whole launch near 512
+// workgroups (two per CU) -- for a batch of 500 images that is one workgroup per image.
 static int hist_blocks_x(long long N, int B) {
-    long long max_by_work = (N + 65535) / 65536;
-    long long want = (2048 + B - 1) / B;
+    long long max_by_work = (N + 262143) / 262144;
+    long long want = (512 + B - 1) / B;
     long long bx = want < max_by_work ? want : max_by_work;
     return (int)(bx < 1 ? 1 : bx);
 }

@@ -142,8 +142,10 @@ __global__ __launch_bounds__(256) void sp_masks_kernel(const uint8_t *__restrict
 
 // HIST: also accumulates the histogram of the output (hist[b][256], zeroed by the launcher, bin 0
 // left empty), for the consumer behind this run.
+// (with the histogram the workgroup is 1024 lanes: its 32 KiB table would otherwise cut the CU down to
+// 16 waves)
 template <bool HIST = false>
-__global__ __launch_bounds__(256) void chain_apply_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(HIST ? 1024 : 256) void chain_apply_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                           long long N, long long in_stride, long long out_stride,
                                                           ChainDesc d, const uint16_t *__restrict__ tables,
                                                           uint32_t *__restrict__ hist = nullptr) {
@@ -932,8 +934,8 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
                 // few, large workgroups: each pays a 32 KiB table and a 256-atomic merge.  The table
                 // prologue above has consumed the old histogram (stream order), so hist2 can be reused.
                 IAK_HIP(hipMemsetAsync(sl.hist2, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
-                dim3 grid(blocks_x((N + 31) / 32, 256, B, 4096), B);
-                hipLaunchKernelGGL((chain_apply_kernel<true>), grid, dim3(256), 0, s, cur, dst, N, N, N, cd, sl.tables, sl.hist2);
+                dim3 grid(blocks_x((N + 31) / 32, 1024, B, 1024), B);
+                hipLaunchKernelGGL((chain_apply_kernel<true>), grid, dim3(1024), 0, s, cur, dst, N, N, N, cd, sl.tables, sl.hist2);
                 IAK_LAUNCH_CHECK();
                 cur_hist = sl.hist2;
                 break;

@@ -229,7 +229,12 @@ __global__ __launch_bounds__(GRAY_THREADS) void gray_kernel(const uint8_t *__res
     if (HIST) hist_flush(sh, hist + (long long)b * 256);
 }
 
-__global__ __launch_bounds__(256) void hist_kernel(const uint8_t *__restrict__ img, uint32_t *__restrict__ hist,
+// 1024 lanes per table, as the grayscale pass: 32 waves per CU instead of the 20 that five
+// 256-lane workgroups with a table each would give, and a fifth of the tables to clear and merge.
+#ifndef HIST_UNROLL
+#define HIST_UNROLL 4
+#endif
+__global__ __launch_bounds__(GRAY_THREADS) void hist_kernel(const uint8_t *__restrict__ img, uint32_t *__restrict__ hist,
                                                    long long N, long long stride) {
     __shared__ uint32_t sh[256 * HIST_COLS];
     const int b = blockIdx.y;
@@ -239,10 +244,22 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t *__restrict__ i
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
     const long long nchunks = N >> 4;
-    for (long long c = tid; c < nchunks; c += nthreads) {
-        u32x4 v = ld16(src + (c << 4));
+    // four chunks per iteration: with one 16-byte load in flight per lane the pass is bound by
+    // memory latency (3 TB/s from HBM), not by the counting
+    for (long long c = tid; c < nchunks; c += HIST_UNROLL * nthreads) {
+        u32x4 v[HIST_UNROLL];
 #pragma unroll
-        for (int w = 0; w < 4; w++) hist_add4(sh, v[w], col);
+        for (int u = 0; u < HIST_UNROLL; u++) {
+            const long long cu = c + u * nthreads;
+            v[u] = ld16<true>(src + ((cu < nchunks ? cu : c) << 4));
+        }
+#pragma unroll
+        for (int u = 0; u < HIST_UNROLL; u++) {
+            if (c + u * nthreads < nchunks) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) hist_add4(sh, v[u][w], col);
+            }
+        }
     }
     const long long scalar_from = nchunks << 4;
     for (long long t = scalar_from + tid; t < N; t += nthreads) atomicAdd(&sh[src[t] * HIST_COLS + col], 1u);
@@ -340,7 +357,7 @@ int iak_hist(const uint8_t *img, uint32_t *hist, long long N, int B, long long s
     hipStream_t s = as_stream(stream);
     IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
     dim3 grid(hist_blocks_x(N, B), B);
-    hipLaunchKernelGGL(hist_kernel, grid, dim3(256), 0, s, img, hist, N, stride);
+    hipLaunchKernelGGL(hist_kernel, grid, dim3(GRAY_THREADS), 0, s, img, hist, N, stride);
     IAK_LAUNCH_CHECK();
     return 0;
 }
