@@ -15,8 +15,40 @@ struct BlockScratch {
     int thr;
 };
 
+// A 64-bit value from the lane that a data-parallel-primitive pattern pairs this lane with
+// (quad_perm / row_mirror / row_half_mirror: register-to-register, no LDS round trip).
+template <int CTRL>
+__device__ __forceinline__ long long dpp_ll(long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((long long)hi << 32) | (long long)(unsigned)lo;
+}
+// lanes 0, 16, 32, 48 of a value whose rows of 16 lanes each hold their row's result
+__device__ __forceinline__ long long row_result(long long v, int row) {
+    const int lo = __builtin_amdgcn_readlane((int)v, 16 * row), hi = __builtin_amdgcn_readlane((int)(v >> 32), 16 * row);
+    return ((long long)hi << 32) | (long long)(unsigned)lo;
+}
+// Sum / maximum over the wave, the same in every lane: a butterfly inside each row of 16 lanes
+// (pairs 1 apart, pairs 2 apart, the two quads of a half row mirrored, the two half rows
+// mirrored), then the four rows.
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+    v += dpp_ll<0xb1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_ll<0x4e>(v);   // quad_perm [2,3,0,1]
+    v += dpp_ll<0x141>(v);  // row_half_mirror
+    v += dpp_ll<0x140>(v);  // row_mirror
+    return row_result(v, 0) + row_result(v, 1) + row_result(v, 2) + row_result(v, 3);
+}
+__device__ __forceinline__ long long max_ll(long long a, long long b) { return a > b ? a : b; }
+__device__ __forceinline__ long long wave_max_ll(long long v) {
+    v = max_ll(v, dpp_ll<0xb1>(v));
+    v = max_ll(v, dpp_ll<0x4e>(v));
+    v = max_ll(v, dpp_ll<0x141>(v));
+    v = max_ll(v, dpp_ll<0x140>(v));
+    return max_ll(max_ll(row_result(v, 0), row_result(v, 1)), max_ll(row_result(v, 2), row_result(v, 3)));
+}
+
 __device__ __forceinline__ long long block_sum_ll(long long v, long long *scratch4) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    v = wave_sum_ll(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch4[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -24,29 +56,35 @@ __device__ __forceinline__ long long block_sum_ll(long long v, long long *scratc
 }
 
 __device__ __forceinline__ long long block_max_ll(long long v, long long *scratch4) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const long long w = __shfl_down(v, o);
-        v = w > v ? w : v;
-    }
+    v = wave_max_ll(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch4[threadIdx.x >> 6] = v;
     __syncthreads();
-    long long m = scratch4[0];
-    for (int i = 1; i < 4; i++) m = scratch4[i] > m ? scratch4[i] : m;
-    return m;
+    return max_ll(max_ll(scratch4[0], scratch4[1]), max_ll(scratch4[2], scratch4[3]));
 }
 
-// inclusive prefix sum over the 256 lanes, wrapping 32-bit arithmetic (as `int` in the reference)
-__device__ __forceinline__ int block_scan_i32(int v, int *buf) {
-    buf[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        int t = (threadIdx.x >= (unsigned)o) ? buf[threadIdx.x - o] : 0;
-        __syncthreads();
-        buf[threadIdx.x] = (int)((unsigned)buf[threadIdx.x] + (unsigned)t);
-        __syncthreads();
+// Inclusive prefix sums of two values over the 256 lanes, wrapping 32-bit arithmetic (as `int` in
+// the reference): a shuffle scan inside each wave, then the totals of the waves before.
+// buf: 8 ints.
+__device__ __forceinline__ void block_scan2_i32(int &a, int &b, int *buf) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ta = __shfl_up(a, o), tb = __shfl_up(b, o);
+        if (lane >= o) {
+            a = (int)((unsigned)a + (unsigned)ta);
+            b = (int)((unsigned)b + (unsigned)tb);
+        }
     }
-    return buf[threadIdx.x];
+    __syncthreads();
+    if (lane == 63) {
+        buf[w] = a;
+        buf[4 + w] = b;
+    }
+    __syncthreads();
+    for (int i = 0; i < w; i++) {
+        a = (int)((unsigned)a + (unsigned)buf[i]);
+        b = (int)((unsigned)b + (unsigned)buf[4 + i]);
+    }
 }
 
 // calculateMeanAndStdDev (imageAnalysis.cu:106-128) from the zero-less histogram: hv = count of
@@ -78,8 +116,8 @@ __device__ __forceinline__ void block_otsu(uint32_t hv, int numPixels, BlockScra
     const int v = threadIdx.x;
     const long long sum64 = block_sum_ll((long long)hv * v, s.red);
     const int sum = (int)sum64;
-    const int nB = block_scan_i32((int)hv, s.ibuf);
-    const int bSum = block_scan_i32((int)((unsigned)v * hv), s.ibuf2);
+    int nB = (int)hv, bSum = (int)((unsigned)v * hv);
+    block_scan2_i32(nB, bSum, s.ibuf);
     const int nF = numPixels - nB;
     float bcv = -1.0f;
     if (nB != 0 && nF != 0) {
@@ -87,19 +125,11 @@ __device__ __forceinline__ void block_otsu(uint32_t hv, int numPixels, BlockScra
         const float fMean = (float)((sum - bSum) / nF);
         bcv = (float)nB * (float)nF * (bMean - fMean) * (bMean - fMean);
     }
-    __syncthreads();
-    s.fbuf[v] = bcv;
-    __syncthreads();
-    if (v == 0) {
-        float varMax = 0;
-        int t = 0;
-        for (int i = 0; i < 256; i++)
-            if (s.fbuf[i] > varMax) {
-                varMax = s.fbuf[i];
-                t = i;
-            }
-        s.thr = t;
-    }
+    // the first bin that attains the largest variance above 0, else bin 0 (:271-275: a strict
+    // comparison against a maximum that starts at 0); positive floats order as their bit patterns
+    const long long key = bcv > 0.0f ? ((long long)__float_as_uint(bcv) << 8) | (long long)(255 - v) : -1;
+    const long long best = block_max_ll(key, s.red);
+    if (v == 0) s.thr = best < 0 ? 0 : 255 - (int)(best & 255);
     __syncthreads();
 }
 

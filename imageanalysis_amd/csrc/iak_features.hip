@@ -17,6 +17,7 @@
 #include "iak_device_fns.hpp"
 #include "iak_common.hpp"
 
+#include <cstddef>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -29,21 +30,78 @@ namespace iak {
 // threshold.  One copy per GPU, held until the process ends; host code reaches it only through
 // the per-device address that features_static_scratch() looks up.
 #define FEAT_STATIC_MAX_IMAGES 1024
+// Look-up tables of the edge count (see perimeter_bits_kernel): built by the statistics kernel,
+// copied into LDS by every workgroup of the edge count.
+struct PerimeterTables {
+    uint8_t two[4096];      // responses of two adjacent pixels, summed
+    uint32_t spread[1024];  // bit i -> bit 3 i
+    uint8_t one[512];       // response of one pixel
+    uint32_t done;          // workgroups of the edge count that have finished
+    uint32_t pad[3];
+};
 struct FeatStaticScratch {
     uint32_t hist[FEAT_STATIC_MAX_IMAGES * 256];
     uint32_t counts[FEAT_STATIC_MAX_IMAGES];
     int32_t thr[FEAT_STATIC_MAX_IMAGES];
+    __attribute__((aligned(16))) PerimeterTables tables;
 };
 static __device__ __align__(256) unsigned char scratch[sizeof(FeatStaticScratch)];
+
+// ---- the edge count on bit masks -----------------------------------------------------------
+// The compass filter runs on the Otsu mask, whose pixels are 0 or 255, so its output at a pixel
+// is a function of the nine mask bits around it.  is255[idx] says whether that output is 255,
+// evaluated once on the host with the filter's own arithmetic (imageAnalysis.cu:592-639: four
+// masks, the running sum carried from mask to mask, the largest |sum| seen, low byte).  The index
+// is column-major: bit 3 * j + i = mask pixel at column offset j - 1, row offset i - 1, so that the
+// indices of neighbouring pixels are overlapping bit fields of one word (see perimeter_bits_kernel).
+struct CompassLut {
+    uint8_t is255[512];
+};
+static CompassLut make_compass_lut() {
+    CompassLut t;
+    for (int idx = 0; idx < 512; idx++) {
+        int p[9];  // row-major, as the filter's masks are written
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) p[3 * i + j] = ((idx >> (3 * j + i)) & 1) * 255;
+        const int s0 = -p[0] + p[2] - 2 * p[3] + 2 * p[5] - p[6] + p[8];
+        const int s1 = -2 * p[0] - p[1] - p[3] + p[5] + p[7] + 2 * p[8];
+        const int s2 = -p[0] - 2 * p[1] - p[2] + p[6] + 2 * p[7] + p[8];
+        const int s3 = -p[1] - 2 * p[2] + p[3] - p[5] + 2 * p[6] + p[7];
+        int sum = s0 < 0 ? -s0 : s0, mx = sum;
+        sum += s1; sum = sum < 0 ? -sum : sum; mx = sum > mx ? sum : mx;
+        sum += s2; sum = sum < 0 ? -sum : sum; mx = sum > mx ? sum : mx;
+        sum += s3; sum = sum < 0 ? -sum : sum; mx = sum > mx ? sum : mx;
+        t.is255[idx] = (mx & 0xff) == 255 ? 1 : 0;
+    }
+    return t;
+}
 
 // One workgroup of 256 lanes per image, lane v = grey value v.
 // features[b] = {mean, std, area, (perimeter: later), mode, rangeMin, rangeMax};
 // counts[b] = 0; thr_out[b] = the Otsu threshold (the mask is pixel > threshold, imageAnalysis.cu:207-216).
+// The workgroup past the last image writes the edge count's tables (tables != nullptr).
 __global__ __launch_bounds__(256) void features_stats_kernel(const uint32_t *__restrict__ hist, int numPixels, int B,
                                                              float *__restrict__ features, uint32_t *__restrict__ counts,
-                                                             int32_t *__restrict__ thr_out) {
+                                                             int32_t *__restrict__ thr_out, PerimeterTables *__restrict__ tables,
+                                                             CompassLut lut) {
     __shared__ BlockScratch bs;
     const int b = blockIdx.x, v = threadIdx.x;
+    if (b == B) {  // uniform over the workgroup
+        uint8_t *one = reinterpret_cast<uint8_t *>(bs.ibuf);
+        if (v == 0) tables->done = 0;
+        for (int i = v; i < 512; i += 256) one[i] = tables->one[i] = lut.is255[i];
+        for (int i = v; i < 1024; i += 256) {
+            uint32_t x = (uint32_t)i;
+            x = (x | (x << 16)) & 0x030000ffu;
+            x = (x | (x << 8)) & 0x0300f00fu;
+            x = (x | (x << 4)) & 0x030c30c3u;
+            x = (x | (x << 2)) & 0x09249249u;
+            tables->spread[i] = x;
+        }
+        __syncthreads();
+        for (int i = v; i < 4096; i += 256) tables->two[i] = one[i & 0x1ff] + one[i >> 3];
+        return;
+    }
     const uint32_t hv = v == 0 ? 0u : hist[(long long)b * 256 + v];  // bin 0 is always empty
     block_mean_std(hv, numPixels, bs);                            // imageMachineLearning.cu:396
     const float mean = bs.ms[0], sd = bs.ms[1];
@@ -72,57 +130,48 @@ __global__ __launch_bounds__(256) void features_stats_kernel(const uint32_t *__r
     }
 }
 
-// perimeter = number of 255s in the compass image of the mask (:362-366), from the counter
-// of the fused pass or from that image's histogram
-__global__ void features_perimeter_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ edge_hist,
-                                          float *__restrict__ features, int B) {
+// perimeter = number of 255s in the compass image of the mask (:362-366), from that image's histogram
+__global__ void features_perimeter_kernel(const uint32_t *__restrict__ edge_hist, float *__restrict__ features, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) features[(long long)b * FEAT_N + 3] = (float)(int)(counts ? counts[b] : edge_hist[(long long)b * 256 + 255]);
+    if (b < B) features[(long long)b * FEAT_N + 3] = (float)(int)edge_hist[(long long)b * 256 + 255];
 }
 
-// ---- the edge count on bit masks -----------------------------------------------------------
-// The compass filter runs on the Otsu mask, whose pixels are 0 or 255, so its output at a pixel
-// is a function of the nine mask bits around it.  kCompass255[idx] says whether that output is
-// 255 (idx bit 3 * i + j = mask pixel at row offset i - 1, column offset j - 1), evaluated once on
-// the host with the filter's own arithmetic (imageAnalysis.cu:592-639: four masks, the running
-// sum carried from mask to mask, the largest |sum| seen, low byte).
-struct CompassLut {
-    uint8_t is255[512];
-};
-static CompassLut make_compass_lut() {
-    CompassLut t;
-    for (int idx = 0; idx < 512; idx++) {
-        int p[9];
-        for (int n = 0; n < 9; n++) p[n] = ((idx >> n) & 1) * 255;
-        const int s0 = -p[0] + p[2] - 2 * p[3] + 2 * p[5] - p[6] + p[8];
-        const int s1 = -2 * p[0] - p[1] - p[3] + p[5] + p[7] + 2 * p[8];
-        const int s2 = -p[0] - 2 * p[1] - p[2] + p[6] + 2 * p[7] + p[8];
-        const int s3 = -p[1] - 2 * p[2] + p[3] - p[5] + 2 * p[6] + p[7];
-        int sum = s0 < 0 ? -s0 : s0, mx = sum;
-        sum += s1; sum = sum < 0 ? -sum : sum; mx = sum > mx ? sum : mx;
-        sum += s2; sum = sum < 0 ? -sum : sum; mx = sum > mx ? sum : mx;
-        sum += s3; sum = sum < 0 ? -sum : sum; mx = sum > mx ? sum : mx;
-        t.is255[idx] = (mx & 0xff) == 255 ? 1 : 0;
-    }
-    return t;
+// The top bit of byte b of the result = byte b of x is above the threshold t: the carry out of the
+// byte-wise sum x + (255 - t), which is the majority of the two top bits and the carry into the top
+// bit.  k7f = (255 - t) & 0x7f and kw = 255 - t in every byte; the other bits of the result are 0.
+__device__ __forceinline__ uint32_t above4_top(uint32_t x, uint32_t k7f, uint32_t kw) {
+    const uint32_t lo = (x & 0x7f7f7f7fu) + k7f;  // top bit of each byte: the carry into it
+    const uint32_t differ = x ^ lo;
+    const uint32_t maj = (differ & kw) | (~differ & x);  // top bits: x and lo agree ? theirs : kw's
+    return maj & 0x80808080u;
 }
 
 // counts[b] += number of pixels whose compass response on the mask (pixel > thr[b]) is 255.
-// A lane owns 8 pixels x 8 rows: ten 16-byte loads, ten 10-bit mask rows, one table look-up
-// per pixel.  Flat view of the image as everywhere: the pixel right of a row's last one is the
-// next row's first, pixels outside the image are 0 (never above a threshold >= 0), and the
-// filter's border (row 0, column 0) is not counted.  W % 8 == 0, images 4-byte aligned.
+// A lane owns 8 pixels x 8 rows: ten 16-byte loads, each turned into the 10 mask bits of
+// columns col0-1 .. col0+8 and spread to every third bit (a 1024-entry table), so that three
+// consecutive rows OR-ed at shifts 0, 1, 2 put the nine bits around pixel p at bits 3p .. 3p+8:
+// the twelve bits from 3p on index a table of the summed responses of pixels p and p + 1 -- one
+// bit-field extract and one LDS byte per two pixels.
+// Flat view of the image as everywhere: the pixel right of a row's last one is the next row's
+// first, pixels outside the image are 0 (never above a threshold >= 0), and the filter's border
+// (row 0, column 0) is not counted.  W % 8 == 0, images 4-byte aligned.
 __global__ __launch_bounds__(256) void perimeter_bits_kernel(const uint8_t *__restrict__ in, int W, int H, long long stride,
                                                              const int32_t *__restrict__ thr, uint32_t *__restrict__ counts,
-                                                             CompassLut lut) {
-    __shared__ uint8_t table[512];
-    for (int i = threadIdx.x; i < 512; i += 256) table[i] = lut.is255[i];
+                                                             PerimeterTables *__restrict__ tables, float *__restrict__ features,
+                                                             int B) {
+    __shared__ __attribute__((aligned(16))) PerimeterTables t;
+    __shared__ bool last;
+    {
+        const u32x4 *from = reinterpret_cast<const u32x4 *>(tables);
+        u32x4 *to = reinterpret_cast<u32x4 *>(&t);
+        for (int i = threadIdx.x; i < (int)(offsetof(PerimeterTables, done) / 16); i += 256) to[i] = from[i];  // the tables only
+    }
     __syncthreads();
     const int b = blockIdx.y;
     const uint8_t *src = in + (long long)b * stride;
     const int N = W * H;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
-    const uint32_t kw = (uint32_t)(255 - thr[b]) * 0x01010101u;
+    const uint32_t kw = (uint32_t)(255 - thr[b]) * 0x01010101u, k7f = kw & 0x7f7f7f7fu;
     const int chunks = W >> 3;
     const int items = chunks * ((H + 7) >> 3);
     uint32_t n255 = 0;
@@ -130,24 +179,41 @@ __global__ __launch_bounds__(256) void perimeter_bits_kernel(const uint8_t *__re
         const int strip = it / chunks;
         const int col0 = (it - strip * chunks) << 3;
         const int y0 = strip << 3;
-        uint32_t bits[10];  // bit i of row r = mask pixel (y0 - 1 + r, col0 - 1 + i)
+        u32x4 v[10];
 #pragma unroll
-        for (int r = 0; r < 10; r++) bits[r] = mask_row10(rsrc, (y0 - 1 + r) * W + col0 - 4, N, kw);
+        for (int r = 0; r < 10; r++) v[r] = load16_flat(rsrc, (y0 - 1 + r) * W + col0 - 4, N);
+        uint32_t s[10];  // bit 3 i of row r = mask pixel (y0 - 1 + r, col0 - 1 + i)
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            // pixels col0-1 .. col0+8 are bytes 3 .. 12 of the load: bytes 3 and 12, then the two words between
+            const uint32_t fe = above4_top(__builtin_amdgcn_perm(v[r][3], v[r][0], 0x0c0c0403u), k7f, kw);
+            const uint32_t f1 = above4_top(v[r][1], k7f, kw), f2 = above4_top(v[r][2], k7f, kw);
+            // the flags are worth 128 each: mask bits 0 .. 4 at bits 7 .. 11 of lo, bits 5 .. 9 at bits 7 .. 11 of hi
+            const uint32_t lo = __builtin_amdgcn_udot4(f1, 0x10080402u, __builtin_amdgcn_udot4(fe, 0x00000001u, 0u, false), false);
+            const uint32_t hi = __builtin_amdgcn_udot4(f2, 0x08040201u, __builtin_amdgcn_udot4(fe, 0x00001000u, 0u, false), false);
+            const uint32_t byte_off = (lo >> 5) | hi;  // 4 * mask
+            s[r] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(t.spread) + byte_off);
+        }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int row = y0 + r;
-            // the three 10-bit rows side by side; rows that are not counted look at nothing
-            uint32_t c = bits[r] | (bits[r + 1] << 10) | (bits[r + 2] << 20);
+            uint32_t c = s[r] | (s[r + 1] << 1) | (s[r + 2] << 2);
             if (row < 1 || row >= H) c = 0;  // index 0: no response
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t hit = table[nine_bits(c, j)];
-                n255 += (j == 0 && col0 == 0) ? 0u : hit;  // column 0 is border
-            }
+            n255 += (uint32_t)t.two[c & 0xfffu] + t.two[(c >> 6) & 0xfffu] + t.two[(c >> 12) & 0xfffu] + t.two[(c >> 18) & 0xfffu];
+            if (col0 == 0) n255 -= t.one[c & 0x1ffu];  // column 0 is border
         }
     }
     for (int o = 32; o > 0; o >>= 1) n255 += __shfl_down(n255, o);
     if ((threadIdx.x & 63) == 0 && n255) atomicAdd(&counts[b], n255);
+    // The workgroup that finishes last turns the counts into the perimeter feature (:362-366): its
+    // ticket is drawn after all of its own additions, and every other workgroup's came before.
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&tables->done, 1u) == gridDim.x * gridDim.y - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    for (int i = threadIdx.x; i < B; i += 256) features[(long long)i * FEAT_N + 3] = (float)(int)atomicAdd(&counts[i], 0u);
 }
 
 // ---- dataset-level sums of one batch, packed for one collective -------------------------------
@@ -372,6 +438,7 @@ long long iak_features_workspace_bytes(int W, int H, int B) {
     bytes += (long long)B * CHAIN_MAX * 256 * 2;  // (reserved)
     bytes += (long long)B * 4 * 2;                // edge counts, thresholds
     bytes = (bytes + 255) & ~255LL;
+    bytes += (sizeof(PerimeterTables) + 255) & ~255LL;
     if (W % 16 != 0 || N >= (1LL << 30)) bytes += 2 * (((long long)B * N + 255) & ~255LL) + (long long)B * 256 * 4;  // mask, edges, their histogram
     return bytes;
 }
@@ -379,7 +446,7 @@ long long iak_features_workspace_bytes(int W, int H, int B) {
 // The one-pass form (W % 16 == 0): statistics from the histogram, the perimeter from one read of
 // the image on bit masks.  own_hist / counts / thr: scratch for B images.
 static int features_one_pass(const uint8_t *img, int W, int H, int B, long long stride, const uint32_t *hist, float *features,
-                             uint32_t *own_hist, uint32_t *counts, int32_t *thr, void *stream) {
+                             uint32_t *own_hist, uint32_t *counts, int32_t *thr, PerimeterTables *tables, void *stream) {
     const long long N = (long long)W * H;
     if ((reinterpret_cast<uintptr_t>(img) & 3u) || stride % 4 != 0) return IAK_E_UNSUPPORTED;
     hipStream_t s = as_stream(stream);
@@ -389,15 +456,13 @@ static int features_one_pass(const uint8_t *img, int W, int H, int B, long long 
         hist = own_hist;
     }
     // also clears counts[0..B)
-    hipLaunchKernelGGL(features_stats_kernel, dim3(B), dim3(256), 0, s, hist, (int)N, B, features, counts, thr);
-    IAK_LAUNCH_CHECK();
     static const CompassLut lut = make_compass_lut();
-    const long long items = (long long)(W >> 3) * ((H + 7) / 8);
-    hipLaunchKernelGGL(perimeter_bits_kernel, dim3(blocks_x(items, 256, B, 1 << 20), B), dim3(256), 0, s, img, W, H, stride,
-                       thr, counts, lut);
+    hipLaunchKernelGGL(features_stats_kernel, dim3(B + 1), dim3(256), 0, s, hist, (int)N, B, features, counts, thr, tables, lut);
     IAK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(features_perimeter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, counts, (const uint32_t *)nullptr,
-                       features, B);
+    const long long items = (long long)(W >> 3) * ((H + 7) / 8);
+    // two work items per lane: a workgroup's copy of the tables costs about a fifth of an item per lane
+    hipLaunchKernelGGL(perimeter_bits_kernel, dim3((unsigned)((items + 511) / 512), B), dim3(256), 0, s, img, W, H,
+                       stride, thr, counts, tables, features, B);
     IAK_LAUNCH_CHECK();
     return 0;
 }
@@ -415,14 +480,18 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
     int32_t *thr = reinterpret_cast<int32_t *>(counts + B);
     size_t head = (size_t)B * 256 * 4 + (size_t)B * CHAIN_MAX * 256 * 2 + (size_t)B * 8;
     head = (head + 255) & ~(size_t)255;
+    PerimeterTables *tables = reinterpret_cast<PerimeterTables *>(ws + head);
+    head += (sizeof(PerimeterTables) + 255) & ~(size_t)255;
     // the workspace for a W % 16 == 0 shape holds no image buffers: the one-pass form is the only one
-    if (W % 16 == 0 && N < (1LL << 30)) return features_one_pass(img, W, H, B, stride, hist, features, own_hist, counts, thr, stream);
+    if (W % 16 == 0 && N < (1LL << 30))
+        return features_one_pass(img, W, H, B, stride, hist, features, own_hist, counts, thr, tables, stream);
     int rc;
     if (!hist) {
         if ((rc = iak_hist(img, own_hist, N, B, stride, stream))) return rc;
         hist = own_hist;
     }
-    hipLaunchKernelGGL(features_stats_kernel, dim3(B), dim3(256), 0, s, hist, (int)N, B, features, counts, thr);
+    hipLaunchKernelGGL(features_stats_kernel, dim3(B), dim3(256), 0, s, hist, (int)N, B, features, counts, thr,
+                       (PerimeterTables *)nullptr, CompassLut());
     IAK_LAUNCH_CHECK();
     // any other shape: the three passes of the reference, on workspace images
     const size_t img_bytes = ((size_t)B * (size_t)N + 255) & ~(size_t)255;
@@ -431,8 +500,7 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
     if ((rc = iak_threshold_per_image(img, mask, N, B, stride, N, thr, stream))) return rc;
     if ((rc = iak_compass(mask, edges, W, H, B, N, N, stream))) return rc;
     if ((rc = iak_hist(edges, edge_hist, N, B, N, stream))) return rc;
-    hipLaunchKernelGGL(features_perimeter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const uint32_t *)nullptr,
-                       edge_hist, features, B);
+    hipLaunchKernelGGL(features_perimeter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, edge_hist, features, B);
     IAK_LAUNCH_CHECK();
     return 0;
 }
@@ -470,7 +538,7 @@ int iak_features_static(const uint8_t *img, int W, int H, int B, long long strid
     FeatStaticScratch *sc = nullptr;
     const int rc = features_static_scratch(&sc);
     if (rc) return rc;
-    return features_one_pass(img, W, H, B, stride, hist, features, sc->hist, sc->counts, sc->thr, stream);
+    return features_one_pass(img, W, H, B, stride, hist, features, sc->hist, sc->counts, sc->thr, &sc->tables, stream);
 }
 
 int iak_dataset_sums(const unsigned long long *hist_sum, const float *features, const int32_t *labels, int B, int C,

@@ -55,12 +55,16 @@ def main():
     ones49 = np.ones(49, np.int32)
     wmed = np.array([1, 2, 1, 2, 3, 2, 1, 2, 1], np.int32)
     g, o = gray.data_ptr(), out.data_ptr()
+    feats = torch.empty((B, 7), dtype=torch.float32, device=dev)
+    fws = torch.empty(int(lib.iak_features_workspace_bytes(W, H, B)) + 256, dtype=torch.uint8, device=dev)
+    fws_ptr = (fws.data_ptr() + 255) & ~255
     cases = {
         "copy(torch)": (lambda: out.copy_(gray), 2),
         "gray": (lambda: lib.iak_gray(rgb.data_ptr(), o, W, H, B, 3 * N, N, 0, st()), 4),
         "gray_avg": (lambda: lib.iak_gray(rgb.data_ptr(), o, W, H, B, 3 * N, N, 1, st()), 4),
         "gray_hist": (lambda: lib.iak_gray_hist(rgb.data_ptr(), o, hist.data_ptr(), W, H, B, 3 * N, N, 0, st()), 5),
         "hist": (lambda: lib.iak_hist(g, hist.data_ptr(), N, B, N, st()), 1),
+        "features": (lambda: lib.iak_features(g, W, H, B, N, hist.data_ptr(), feats.data_ptr(), fws_ptr, st()), 1),
         "apply_map": (lambda: lib.iak_apply_map(g, o, N, B, N, N, m.data_ptr(), 256, st()), 2),
         "threshold": (lambda: lib.iak_threshold(g, o, N, B, N, N, 100, st()), 2),
         "salt_pepper": (lambda: lib.iak_salt_pepper(g, o, N, B, N, N, sp.data_ptr(), st()), 3),
