@@ -36,12 +36,10 @@ struct PerimeterTables {
     uint8_t two[4096];      // responses of two adjacent pixels, summed
     uint32_t spread[1024];  // bit i -> bit 3 i
     uint8_t one[512];       // response of one pixel
-    uint32_t done;          // workgroups of the edge count that have finished
-    uint32_t pad[3];
 };
 struct FeatStaticScratch {
     uint32_t hist[FEAT_STATIC_MAX_IMAGES * 256];
-    uint32_t counts[FEAT_STATIC_MAX_IMAGES];
+    unsigned long long counts[FEAT_STATIC_MAX_IMAGES];
     int32_t thr[FEAT_STATIC_MAX_IMAGES];
     __attribute__((aligned(16))) PerimeterTables tables;
 };
@@ -81,14 +79,13 @@ static CompassLut make_compass_lut() {
 // counts[b] = 0; thr_out[b] = the Otsu threshold (the mask is pixel > threshold, imageAnalysis.cu:207-216).
 // The workgroup past the last image writes the edge count's tables (tables != nullptr).
 __global__ __launch_bounds__(256) void features_stats_kernel(const uint32_t *__restrict__ hist, int numPixels, int B,
-                                                             float *__restrict__ features, uint32_t *__restrict__ counts,
+                                                             float *__restrict__ features, unsigned long long *__restrict__ counts,
                                                              int32_t *__restrict__ thr_out, PerimeterTables *__restrict__ tables,
                                                              CompassLut lut) {
     __shared__ BlockScratch bs;
     const int b = blockIdx.x, v = threadIdx.x;
     if (b == B) {  // uniform over the workgroup
         uint8_t *one = reinterpret_cast<uint8_t *>(bs.ibuf);
-        if (v == 0) tables->done = 0;
         for (int i = v; i < 512; i += 256) one[i] = tables->one[i] = lut.is255[i];
         for (int i = v; i < 1024; i += 256) {
             uint32_t x = (uint32_t)i;
@@ -156,15 +153,16 @@ __device__ __forceinline__ uint32_t above4_top(uint32_t x, uint32_t k7f, uint32_
 // first, pixels outside the image are 0 (never above a threshold >= 0), and the filter's border
 // (row 0, column 0) is not counted.  W % 8 == 0, images 4-byte aligned.
 __global__ __launch_bounds__(256) void perimeter_bits_kernel(const uint8_t *__restrict__ in, int W, int H, long long stride,
-                                                             const int32_t *__restrict__ thr, uint32_t *__restrict__ counts,
-                                                             PerimeterTables *__restrict__ tables, float *__restrict__ features,
-                                                             int B) {
+                                                             const int32_t *__restrict__ thr,
+                                                             unsigned long long *__restrict__ counts,
+                                                             const PerimeterTables *__restrict__ tables,
+                                                             float *__restrict__ features) {
     __shared__ __attribute__((aligned(16))) PerimeterTables t;
-    __shared__ bool last;
+    __shared__ uint32_t part[4];
     {
         const u32x4 *from = reinterpret_cast<const u32x4 *>(tables);
         u32x4 *to = reinterpret_cast<u32x4 *>(&t);
-        for (int i = threadIdx.x; i < (int)(offsetof(PerimeterTables, done) / 16); i += 256) to[i] = from[i];  // the tables only
+        for (int i = threadIdx.x; i < (int)(sizeof(PerimeterTables) / 16); i += 256) to[i] = from[i];
     }
     __syncthreads();
     const int b = blockIdx.y;
@@ -204,16 +202,18 @@ __global__ __launch_bounds__(256) void perimeter_bits_kernel(const uint8_t *__re
         }
     }
     for (int o = 32; o > 0; o >>= 1) n255 += __shfl_down(n255, o);
-    if ((threadIdx.x & 63) == 0 && n255) atomicAdd(&counts[b], n255);
-    // The workgroup that finishes last turns the counts into the perimeter feature (:362-366): its
-    // ticket is drawn after all of its own additions, and every other workgroup's came before.
-    __threadfence();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n255;
     __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(&tables->done, 1u) == gridDim.x * gridDim.y - 1;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    for (int i = threadIdx.x; i < B; i += 256) features[(long long)i * FEAT_N + 3] = (float)(int)atomicAdd(&counts[i], 0u);
+    // One 64-bit atomic per workgroup carries its count (low 40 bits; N < 2^30) and a ticket (the
+    // bits above): the value that comes back tells the image's last workgroup that it is the last,
+    // and what the others had counted -- it writes the perimeter feature (:362-366).  No fence, no
+    // second look at memory.
+    if (threadIdx.x == 0) {
+        const unsigned long long mine = (unsigned long long)part[0] + part[1] + part[2] + part[3];
+        const unsigned long long before = atomicAdd(&counts[b], mine | (1ull << 40));
+        if ((before >> 40) == gridDim.x - 1)
+            features[(long long)b * FEAT_N + 3] = (float)(int)((before & ((1ull << 40) - 1)) + mine);
+    }
 }
 
 // ---- dataset-level sums of one batch, packed for one collective -------------------------------
@@ -436,7 +436,7 @@ long long iak_features_workspace_bytes(int W, int H, int B) {
     long long bytes = 0;
     bytes += (long long)B * 256 * 4;              // histogram of the image
     bytes += (long long)B * CHAIN_MAX * 256 * 2;  // (reserved)
-    bytes += (long long)B * 4 * 2;                // edge counts, thresholds
+    bytes += (long long)B * (8 + 4);              // edge counts, thresholds
     bytes = (bytes + 255) & ~255LL;
     bytes += (sizeof(PerimeterTables) + 255) & ~255LL;
     if (W % 16 != 0 || N >= (1LL << 30)) bytes += 2 * (((long long)B * N + 255) & ~255LL) + (long long)B * 256 * 4;  // mask, edges, their histogram
@@ -446,7 +446,7 @@ long long iak_features_workspace_bytes(int W, int H, int B) {
 // The one-pass form (W % 16 == 0): statistics from the histogram, the perimeter from one read of
 // the image on bit masks.  own_hist / counts / thr: scratch for B images.
 static int features_one_pass(const uint8_t *img, int W, int H, int B, long long stride, const uint32_t *hist, float *features,
-                             uint32_t *own_hist, uint32_t *counts, int32_t *thr, PerimeterTables *tables, void *stream) {
+                             uint32_t *own_hist, unsigned long long *counts, int32_t *thr, PerimeterTables *tables, void *stream) {
     const long long N = (long long)W * H;
     if ((reinterpret_cast<uintptr_t>(img) & 3u) || stride % 4 != 0) return IAK_E_UNSUPPORTED;
     hipStream_t s = as_stream(stream);
@@ -462,7 +462,7 @@ static int features_one_pass(const uint8_t *img, int W, int H, int B, long long 
     const long long items = (long long)(W >> 3) * ((H + 7) / 8);
     // two work items per lane: a workgroup's copy of the tables costs about a fifth of an item per lane
     hipLaunchKernelGGL(perimeter_bits_kernel, dim3((unsigned)((items + 511) / 512), B), dim3(256), 0, s, img, W, H,
-                       stride, thr, counts, tables, features, B);
+                       stride, thr, counts, tables, features);
     IAK_LAUNCH_CHECK();
     return 0;
 }
@@ -476,9 +476,9 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
     hipStream_t s = as_stream(stream);
     uint8_t *ws = static_cast<uint8_t *>(workspace);
     uint32_t *own_hist = reinterpret_cast<uint32_t *>(ws);
-    uint32_t *counts = reinterpret_cast<uint32_t *>(ws + (size_t)B * 256 * 4 + (size_t)B * CHAIN_MAX * 256 * 2);
+    unsigned long long *counts = reinterpret_cast<unsigned long long *>(ws + (size_t)B * 256 * 4 + (size_t)B * CHAIN_MAX * 256 * 2);
     int32_t *thr = reinterpret_cast<int32_t *>(counts + B);
-    size_t head = (size_t)B * 256 * 4 + (size_t)B * CHAIN_MAX * 256 * 2 + (size_t)B * 8;
+    size_t head = (size_t)B * 256 * 4 + (size_t)B * CHAIN_MAX * 256 * 2 + (size_t)B * 12;
     head = (head + 255) & ~(size_t)255;
     PerimeterTables *tables = reinterpret_cast<PerimeterTables *>(ws + head);
     head += (sizeof(PerimeterTables) + 255) & ~(size_t)255;
