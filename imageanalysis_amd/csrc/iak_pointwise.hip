@@ -26,9 +26,14 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const uint8_t *__restric
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
     const long long nchunks = N >> 4;
-    for (long long c = tid; c < nchunks; c += nthreads) {
-        u32x4 v = ld16<IAK_NT_CHAIN_LD>(src + (c << 4));
-        st16<IAK_NT_CHAIN_ST>(dst + (c << 4), f.apply16(v, c << 4));
+    // two chunks per iteration: both loads are in flight before the first is used
+    for (long long c = tid; c < nchunks; c += 2 * nthreads) {
+        const long long c1 = c + nthreads;
+        const bool two = c1 < nchunks;
+        const u32x4 v0 = ld16<IAK_NT_CHAIN_LD>(src + (c << 4));
+        const u32x4 v1 = ld16<IAK_NT_CHAIN_LD>(src + ((two ? c1 : c) << 4));
+        st16<IAK_NT_CHAIN_ST>(dst + (c << 4), f.apply16(v0, c << 4));
+        if (two) st16<IAK_NT_CHAIN_ST>(dst + (c1 << 4), f.apply16(v1, c1 << 4));
     }
     for (long long t = (nchunks << 4) + tid; t < N; t += nthreads) dst[t] = (uint8_t)f.apply1(src[t], t);
 }
