@@ -188,7 +188,7 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
  * the reference: it is for callers that cannot allocate device memory or carry a workspace --
  * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
  * results as iak_features.  Its scratch (per image: a 256-bin histogram, an edge counter, a
- * threshold; about 1 MiB) is a fixed array inside the library, one copy per GPU, held until the
+ * threshold; once: the edge count's look-up tables; about 1 MiB in all) is a fixed array inside the library, one copy per GPU, held until the
  * process ends.  Limits: B <= iak_features_static_max_images() (1024; more returns
  * IAK_E_TOO_LARGE), W % 16 == 0 and 4-byte aligned images and stride (IAK_E_UNSUPPORTED otherwise:
  * the other shapes need image-sized scratch).  Every call on a GPU uses that GPU's one array, so
