@@ -15,6 +15,7 @@
 #include "iak_stencil_ops.hpp"
 #include "iak_stencil_tiled.hpp"
 #include "iak_morph_chain.hpp"
+#include "iak_morph_rows.hpp"
 
 namespace iak {
 
@@ -516,6 +517,8 @@ static int morph(const uint8_t *in, uint8_t *out, int W, int H, int B, long long
     const int a = (kH - 1) / 2, s = (kW - 1) / 2;
     const int visited = (2 * a + 1) * (2 * s + 1);
     for (int i = 0; i < visited; i++) t.v[i] = se[i];
+    rc = launch_morph_rows(in, out, W, H, B, in_stride, out_stride, t.v, 2 * s + 1, 2 * a + 1, erode, as_stream(stream));
+    if (rc != IAK_E_UNSUPPORTED) return rc;
     rc = launch_tiled_morph(in, out, W, H, B, in_stride, out_stride, t.v, 2 * s + 1, 2 * a + 1, erode, as_stream(stream));
     if (rc != IAK_E_UNSUPPORTED) return rc;
     if (erode)

@@ -416,6 +416,10 @@ SES = {
     "even43": (4, 3, [1, 0, 1, 1, 0, 1, 1, 0, 1, 1, 0, 0]),
     "rand7x3": (7, 3, [1, 0, 0, 1, 0, 1, 1, 0, 1, 0, 0, 0, 1, 0, 1, 0, 1, 1, 0, 0, 1]),
     "sparse9": (9, 9, [1 if (i * 7) % 11 == 0 else 0 for i in range(81)]),
+    "ones7": (7, 7, [1] * 49),
+    "box9x3": (9, 3, [1] * 27),
+    "line3x9": (3, 9, [1, 0, 1] * 9),
+    "disk5": (5, 5, [0, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 0]),
     "ones25": (25, 25, [1] * 625),
     "corners25": (25, 25, [1 if i in (0, 24, 600, 624, 312) else 0 for i in range(625)]),
 }
