@@ -294,6 +294,10 @@ __global__ __launch_bounds__(256) void box_special_kernel(const uint8_t *__restr
     }
 }
 
+}  // namespace iak
+#include "iak_box_rows.hpp"
+namespace iak {
+
 // kW, kH: the odd window actually visited (at most 25 x 25); w its one weight; divisor: for the
 // average filter.  IAK_E_UNSUPPORTED when the path does not apply.
 static int launch_box_sum(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
@@ -309,6 +313,10 @@ static int launch_box_sum(const uint8_t *in, uint8_t *out, int W, int H, int B, 
         memo = m;
     }
     if (memo.kind == BOX_NO) return IAK_E_UNSUPPORTED;
+    if (memo.kind == BOX_PLAIN) {  // square windows up to 9 x 9: in registers
+        const int rc = launch_box_rows(in, out, W, H, B, in_stride, out_stride, kW, kH, w, divisor, avg, s);
+        if (rc != IAK_E_UNSUPPORTED) return rc;
+    }
     const int tiles_x = (W + BX_T - 1) / BX_T, tiles_y = (H + BX_T - 1) / BX_T;
     const dim3 grid((unsigned)(tiles_x * tiles_y), B);
     if (memo.kind == BOX_SPECIAL) {

@@ -269,8 +269,8 @@ def test_linear_tiled(ops, kW, kH, W, H, kind):
 
 
 @pytest.mark.parametrize("w", [1.0 / 121, 1.0 / 25, 1.0, 0.5, 0.999, 1.0 / 3, 2.5, 3.7, 0.0078125, 1e-3])
-@pytest.mark.parametrize("kW,kH", [(11, 11), (5, 5), (25, 25), (7, 3), (1, 9), (4, 6)])
-@pytest.mark.parametrize("W,H,kind", [(200, 70, "C"), (131, 150, "U"), (64, 64, "K"), (9, 40, "U")])
+@pytest.mark.parametrize("kW,kH", [(11, 11), (5, 5), (25, 25), (7, 3), (1, 9), (4, 6), (7, 7), (9, 9), (8, 8)])
+@pytest.mark.parametrize("W,H,kind", [(200, 70, "C"), (131, 150, "U"), (64, 64, "K"), (9, 40, "U"), (16, 5, "U"), (8, 19, "C")])
 def test_box_filters(ops, w, kW, kH, W, H, kind):
     # every tap the same weight: integer box sums where the per-tap truncation provably commutes
     # with the sum, the tap-by-tap kernels otherwise (weights near an integer from below, big sums)
