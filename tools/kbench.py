@@ -53,6 +53,10 @@ def main():
     box11 = np.full(121, 1.0 / 121, np.float32)
     ones25f = np.ones(25, np.float32)
     ones49 = np.ones(49, np.int32)
+    ones81 = np.ones(81, np.int32)
+    disk9 = np.array([1 if (i // 9 - 4) ** 2 + (i % 9 - 4) ** 2 <= 18 else 0 for i in range(81)], np.int32)
+    ones81f = np.ones(81, np.float32)
+    box7 = np.full(49, 0.02, np.float32)
     wmed = np.array([1, 2, 1, 2, 3, 2, 1, 2, 1], np.int32)
     g, o = gray.data_ptr(), out.data_ptr()
     feats = torch.empty((B, 7), dtype=torch.float32, device=dev)
@@ -85,6 +89,10 @@ def main():
         "median5": (lambda: lib.iak_median(g, o, W, H, B, N, N, ones49.ctypes.data, 5, 5, st()), 2),
         "erode5": (lambda: lib.iak_erode(g, o, W, H, B, N, N, ones49.ctypes.data, 5, 5, st()), 2),
         "dilate5": (lambda: lib.iak_dilate(g, o, W, H, B, N, N, ones49.ctypes.data, 5, 5, st()), 2),
+        "erode9": (lambda: lib.iak_erode(g, o, W, H, B, N, N, ones81.ctypes.data, 9, 9, st()), 2),
+        "dilate9_disk": (lambda: lib.iak_dilate(g, o, W, H, B, N, N, disk9.ctypes.data, 9, 9, st()), 2),
+        "average9": (lambda: lib.iak_linear(g, o, W, H, B, N, N, ones81f.ctypes.data, 9, 9, 1, st()), 2),
+        "box7_frac": (lambda: lib.iak_linear(g, o, W, H, B, N, N, box7.ctypes.data, 7, 7, 0, st()), 2),
     }
     only = [x for x in args.only.split(",") if x]
     names = [n for n in cases if not only or n in only]
