@@ -426,7 +426,7 @@ SES = {
 
 
 @pytest.mark.parametrize("se", list(SES))
-@pytest.mark.parametrize("W,H", SIZES + [(200, 70), (131, 45)])
+@pytest.mark.parametrize("W,H", SIZES + [(200, 70), (131, 45), (8, 11), (24, 2)])
 def test_morphology(ops, se, W, H):
     kW, kH, v = SES[se]
     rs = np.random.default_rng(5)
