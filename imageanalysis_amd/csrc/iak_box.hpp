@@ -129,10 +129,58 @@ __device__ __forceinline__ void box_stage_tile(uint16_t *t1, __amdgpu_buffer_rsr
     }
 }
 
+// The same tile staged four pixels per load, for images whose rows start at multiples of 4 bytes
+// (W % 4 == 0, 4-byte aligned images).  The byte-wise form above spends 40 % of the special
+// kernel's time (one load, one offset clamp, one LDS store per pixel).  Here the tile starts
+// SH = s rounded up to a multiple of 4 columns left of x0, so that every dword is aligned and
+// wholly inside or outside the image (N % 4 == 0); tile column c of the form above is column
+// c + SH - s here.  IWs: staged columns, a multiple of 4.  Eight loads per lane are issued before
+// the first is used.
+template <bool SPECIAL>
+__device__ __forceinline__ void box_stage_tile_wide(uint16_t *t1, __amdgpu_buffer_rsrc_t rsrc, int N, int W, int x0, int y0,
+                                                    int a, int SH, int IWs, int IH, float w, const uint16_t *lut) {
+    const int DW = IWs >> 2;
+    const int tasks = IH * DW;
+    // task t = (row t / DW, dword t % DW); a lane's tasks are 256 apart: one division, then steps
+    const int step_r = 256 / DW, step_d = 256 - step_r * DW;
+    int r0 = (int)threadIdx.x / DW, d0 = (int)threadIdx.x - r0 * DW;
+    for (int t0 = threadIdx.x; t0 < tasks; t0 += 8 * 256) {
+        uint32_t v[8];
+        int r = r0, d = d0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int f = (y0 - a + r) * W + x0 - SH + 4 * d;
+            // tasks past the tile and offsets outside [0, N) (negative ones as unsigned) read 0
+            const uint32_t o = t0 + 256 * u < tasks ? min((uint32_t)f, (uint32_t)N) : (uint32_t)N;
+            v[u] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o, 0, 0);
+            r += step_r; d += step_d;
+            if (d >= DW) { d -= DW; r++; }
+        }
+        r = r0; d = d0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (t0 + 256 * u < tasks) {
+                uint32_t e[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t px = (v[u] >> (8 * k)) & 0xffu;
+                    e[k] = SPECIAL ? (uint32_t)lut[px] : (uint32_t)(uint16_t)(uint32_t)((float)px * w);
+                }
+                uint32_t *q = reinterpret_cast<uint32_t *>(t1 + r * BX_PITCH + 4 * d);  // BX_PITCH is even
+                q[0] = e[0] | (e[1] << 16);
+                q[1] = e[2] | (e[3] << 16);
+            }
+            r += step_r; d += step_d;
+            if (d >= DW) { d -= DW; r++; }
+        }
+        r0 = r; d0 = d;
+    }
+}
+
 template <bool AVG>
 __global__ __launch_bounds__(256) void box_sum_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W, int H,
                                                       long long in_stride, long long out_stride, int kW, int kH, float w,
-                                                      int divisor, int tiles_x) {
+                                                      int divisor, int tiles_x, bool wide) {
     __shared__ __attribute__((aligned(16))) uint16_t t1[BX_IN * BX_PITCH];  // floor(pixel * w)
     __shared__ __attribute__((aligned(16))) uint16_t t2[BX_T * BX_PITCH];   // vertical sums
     const int N = W * H;  // the launcher keeps W * (H + 32) below 2^31
@@ -142,8 +190,17 @@ __global__ __launch_bounds__(256) void box_sum_kernel(const uint8_t *__restrict_
     const int a = (kH - 1) / 2, s = (kW - 1) / 2;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int x0 = tx * BX_T, y0 = ty * BX_T;
-    const int IW = BX_T + kW - 1, IH = BX_T + kH - 1;
-    box_stage_tile<false>(t1, rsrc, N, W, x0, y0, a, s, IW, IH, w, nullptr);
+    int IW = BX_T + kW - 1;
+    const int IH = BX_T + kH - 1;
+    int sh = 0;  // tile column 0 (image column x0 - s) sits at staged column sh
+    if (wide) {
+        const int SH = (s + 3) & ~3;
+        sh = SH - s;
+        IW = (BX_T + SH + s + 3) & ~3;
+        box_stage_tile_wide<false>(t1, rsrc, N, W, x0, y0, a, SH, IW, IH, w, nullptr);
+    } else {
+        box_stage_tile<false>(t1, rsrc, N, W, x0, y0, a, s, IW, IH, w, nullptr);
+    }
     __syncthreads();
     // (B) column pairs x four segments of 16 output rows: sliding sums of kH rows.  Two 16-bit
     // sums travel in one word; a carry from the low half into the high one during an add is
@@ -171,7 +228,7 @@ __global__ __launch_bounds__(256) void box_sum_kernel(const uint8_t *__restrict_
     const int y = threadIdx.x >> 2, q = threadIdx.x & 3;
     const int row = y0 + y, col0 = x0 + 16 * q;
     if (row >= H || col0 >= W) return;
-    const uint16_t *rowp = t2 + y * BX_PITCH + 16 * q;
+    const uint16_t *rowp = t2 + y * BX_PITCH + 16 * q + sh;
     uint32_t acc = 0;
     for (int j = 0; j < kW; j++) acc += rowp[j];
     uint32_t o[16];
@@ -213,14 +270,18 @@ __global__ __launch_bounds__(256) void box_sum_kernel(const uint8_t *__restrict_
 // this row": restarted from G at a row with a contributing tap, grown by the row's specials
 // otherwise.  No branches on the pixel data.
 #define BXS_PITCH (BX_T + 1)
+#ifndef BXS_TY
+#define BXS_TY 64  // tile height of the special form (its width is BX_T)
+#endif
+#define BXS_SEG (BXS_TY / 4)
 // KW is a template parameter so that the row passes unroll and their LDS reads travel together.
 template <bool AVG, int KW>
 __global__ __launch_bounds__(256) void box_special_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
                                                           int H, long long in_stride, long long out_stride, int kH,
-                                                          float w, int divisor, int tiles_x, BoxSpecial sp) {
+                                                          float w, int divisor, int tiles_x, BoxSpecial sp, bool wide) {
     constexpr int kW = KW;
-    __shared__ __attribute__((aligned(16))) uint16_t t1[BX_IN * BX_PITCH];  // per pixel: floor | special | contributing
-    __shared__ uint32_t t2[(BX_T + 14) * BXS_PITCH];                        // per input row and column: see above
+    __shared__ __attribute__((aligned(16))) uint16_t t1[(BXS_TY + 14) * BX_PITCH];  // per pixel: floor | special | contributing
+    __shared__ uint32_t t2[(BXS_TY + 14) * BXS_PITCH];                        // per input row and column: see above
     __shared__ uint16_t lut[256];
     {
         const uint32_t px = threadIdx.x;
@@ -235,14 +296,21 @@ __global__ __launch_bounds__(256) void box_special_kernel(const uint8_t *__restr
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
     const int a = (kH - 1) / 2, s = (kW - 1) / 2;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int x0 = tx * BX_T, y0 = ty * BX_T;
-    const int IW = BX_T + kW - 1, IH = BX_T + kH - 1;
-    box_stage_tile<true>(t1, rsrc, N, W, x0, y0, a, s, IW, IH, w, lut);
+    const int x0 = tx * BX_T, y0 = ty * BXS_TY;
+    const int IW = BX_T + kW - 1, IH = BXS_TY + kH - 1;
+    int sh = 0;  // tile column 0 (image column x0 - s) sits at staged column sh
+    if (wide) {
+        const int SH = (s + 3) & ~3;
+        sh = SH - s;
+        box_stage_tile_wide<true>(t1, rsrc, N, W, x0, y0, a, SH, (BX_T + SH + s + 3) & ~3, IH, w, lut);
+    } else {
+        box_stage_tile<true>(t1, rsrc, N, W, x0, y0, a, s, IW, IH, w, lut);
+    }
     __syncthreads();
     // (B) IH rows x 8 chunks of 8 outputs
     for (int task = threadIdx.x; task < IH * 8; task += 256) {
         const int r = task >> 3, c0 = (task & 7) << 3;
-        const uint16_t *rowp = t1 + r * BX_PITCH + c0;
+        const uint16_t *rowp = t1 + r * BX_PITCH + c0 + sh;
         uint32_t el[8 + KW - 1];  // the chunk's 8 windows
 #pragma unroll
         for (int c = 0; c < 8 + KW - 1; c++) el[c] = rowp[c];
@@ -264,11 +332,11 @@ __global__ __launch_bounds__(256) void box_special_kernel(const uint8_t *__restr
         }
     }
     __syncthreads();
-    // (C) 64 columns x 4 segments of 16 rows, bottom row first
+    // (C) 64 columns x 4 segments of BXS_SEG rows, bottom row first
     const int x = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const int col = x0 + x;
     if (col >= W) return;
-    const uint32_t *colp = t2 + (seg * 16) * BXS_PITCH + x;
+    const uint32_t *colp = t2 + (seg * BXS_SEG) * BXS_PITCH + x;
     uint32_t acc = 0, before = 0;
     auto step = [&](uint32_t e) {  // one row further up
         acc += e;
@@ -276,12 +344,12 @@ __global__ __launch_bounds__(256) void box_special_kernel(const uint8_t *__restr
     };
     // the window of the segment's last row, but for its top row, which the loop below adds
 #pragma unroll 4
-    for (int r = 15 + kH - 1; r > 15; r--) step(colp[r * BXS_PITCH]);
+    for (int r = BXS_SEG - 1 + kH - 1; r > BXS_SEG - 1; r--) step(colp[r * BXS_PITCH]);
 #pragma unroll
-    for (int i = 15; i >= 0; i--) {
+    for (int i = BXS_SEG - 1; i >= 0; i--) {
         step(colp[i * BXS_PITCH]);
-        if (i < 15) acc -= colp[(i + kH) * BXS_PITCH];
-        const int row = y0 + seg * 16 + i;
+        if (i < BXS_SEG - 1) acc -= colp[(i + kH) * BXS_PITCH];
+        const int row = y0 + seg * BXS_SEG + i;
         if (row >= H) continue;
         uint32_t sum = acc & 0x3ffu;
         const uint32_t n_special = (acc >> 10) & 0xffu, n_big = (acc >> 18) & 0xffu;
@@ -319,15 +387,18 @@ static int launch_box_sum(const uint8_t *in, uint8_t *out, int W, int H, int B, 
     }
     const int tiles_x = (W + BX_T - 1) / BX_T, tiles_y = (H + BX_T - 1) / BX_T;
     const dim3 grid((unsigned)(tiles_x * tiles_y), B);
+    // rows that start at multiples of 4 bytes: the tile is staged a dword at a time
+    const bool wide = W % 4 == 0 && reinterpret_cast<uintptr_t>(in) % 4 == 0 && in_stride % 4 == 0;
     if (memo.kind == BOX_SPECIAL) {
+        const dim3 grid((unsigned)(tiles_x * ((H + BXS_TY - 1) / BXS_TY)), B);
 #define BXS_CASE(K)                                                                                                       \
     case K:                                                                                                               \
         if (avg)                                                                                                          \
             hipLaunchKernelGGL((box_special_kernel<true, K>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, kH, w, \
-                               divisor, tiles_x, memo.sp);                                                                \
+                               divisor, tiles_x, memo.sp, wide);                                                          \
         else                                                                                                              \
             hipLaunchKernelGGL((box_special_kernel<false, K>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, kH, \
-                               w, divisor, tiles_x, memo.sp);                                                             \
+                               w, divisor, tiles_x, memo.sp, wide);                                                       \
         break;
         switch (kW) {
             BXS_CASE(1) BXS_CASE(3) BXS_CASE(5) BXS_CASE(7) BXS_CASE(9) BXS_CASE(11) BXS_CASE(13) BXS_CASE(15)
@@ -336,10 +407,10 @@ static int launch_box_sum(const uint8_t *in, uint8_t *out, int W, int H, int B, 
 #undef BXS_CASE
     } else if (avg) {
         hipLaunchKernelGGL(box_sum_kernel<true>, grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, kW, kH, w, divisor,
-                           tiles_x);
+                           tiles_x, wide);
     } else {
         hipLaunchKernelGGL(box_sum_kernel<false>, grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, kW, kH, w, divisor,
-                           tiles_x);
+                           tiles_x, wide);
     }
     IAK_LAUNCH_CHECK();
     return 0;
