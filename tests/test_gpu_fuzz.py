@@ -26,16 +26,18 @@ def random_op(rs):
     elif t == O.OP_SALT_PEPPER:
         op["iparam"] = int(rs.choice([0, 1, 5, 50, 255]))
     elif t in (O.OP_LINEAR, O.OP_AVERAGE):
-        k = int(rs.choice([3, 3, 3, 5, 1, 2]))
-        kind = rs.integers(0, 4)
+        k = int(rs.choice([3, 3, 3, 5, 1, 2, 7, 9]))
+        kind = rs.integers(0, 5) if k <= 5 else rs.integers(3, 5)
         if kind == 0:
             w = rs.integers(-3, 12, k * k).astype(np.float32)
         elif kind == 1:
             w = (rs.integers(0, 9, k * k) / 16.0).astype(np.float32)
         elif kind == 2:
             w = ((rs.random(k * k) - 0.3) * 1.5).astype(np.float32)
-        else:
+        elif kind == 3:
             w = np.full(k * k, 1.0 / (k * k), np.float32)
+        else:
+            w = np.full(k * k, float(rs.choice([1.0, 0.5, 0.03])), np.float32)
         op.update(kW=k, kH=k, fkernel=[float(v) for v in w])
     elif t == O.OP_MEDIAN:
         kw, kh = (3, 3) if rs.random() < 0.6 else (int(rs.choice([1, 3, 5, 7])), int(rs.choice([1, 3, 5])))
@@ -44,8 +46,9 @@ def random_op(rs):
             w[0] = 1
         op.update(kW=kw, kH=kh, ikernel=w)
     elif t in (O.OP_DILATE, O.OP_ERODE):
-        kw, kh = (3, 3) if rs.random() < 0.7 else (int(rs.choice([1, 3, 5])), int(rs.choice([1, 3, 5])))
-        op.update(kW=kw, kH=kh, ikernel=[int(v) for v in rs.integers(0, 2, kw * kh)])
+        kw, kh = (3, 3) if rs.random() < 0.6 else (int(rs.choice([1, 3, 5, 7, 9])), int(rs.choice([1, 3, 5, 7, 9])))
+        se = [int(v) for v in rs.integers(0, 2, kw * kh)] if rs.random() < 0.6 else [1] * (kw * kh)
+        op.update(kW=kw, kH=kh, ikernel=se)
     elif t == O.OP_THRESHOLD:
         op["iparam"] = int(rs.integers(-1, 257))
     elif t == O.OP_QUANTIZE:
@@ -58,7 +61,7 @@ def random_op(rs):
     return op
 
 
-@pytest.mark.parametrize("case", range(250))
+@pytest.mark.parametrize("case", range(300))
 def test_fuzz_pipeline(case):
     from imageanalysis_amd.pipeline import Pipeline
     rs = np.random.default_rng(9000 + case)
@@ -108,11 +111,11 @@ def _placed(imgs, rs):
     return view
 
 
-@pytest.mark.parametrize("case", range(120))
+@pytest.mark.parametrize("case", range(260))
 def test_fuzz_entry_points(case):
     from imageanalysis_amd import ops
     rs = np.random.default_rng(5000 + case)
-    W = int(rs.choice([16, 32, 64, 128])) if rs.random() < 0.5 else int(rs.integers(1, 70))
+    W = int(rs.choice([8, 16, 24, 32, 64, 128, 200])) if rs.random() < 0.6 else int(rs.integers(1, 70))
     H = int(rs.integers(1, 40))
     B = int(rs.integers(1, 4))
     kind = str(rs.choice(["C", "U", "K"]))
@@ -131,7 +134,7 @@ def test_fuzz_entry_points(case):
             want = want[0] if isinstance(want, tuple) else want
             assert np.array_equal(got[b], want), f"case {case} {what} {W}x{H} image {b} offset {x.data_ptr() % 16} stride {x.stride(0)}"
 
-    which = int(rs.integers(0, 12))
+    which = int(rs.integers(0, 13))
     if which == 0:
         check(ops.calculateHistogram(x), O.hist, "hist")
         check(ops.histogramEqualization(x), O.equalize, "equalize")
@@ -169,10 +172,22 @@ def test_fuzz_entry_points(case):
         check(ops.sobelFilter(x), O.sobel, "sobel")
         check(ops.compassFilter(x), O.compass, "compass")
     elif which == 9:
-        kw, kh = (3, 3) if rs.random() < 0.6 else (5, 3)
-        se = [int(v) for v in rs.integers(0, 2, kw * kh)]
+        kw, kh = (3, 3) if rs.random() < 0.4 else (int(rs.choice([1, 3, 5, 7, 9, 4])), int(rs.choice([1, 3, 5, 7, 9, 6])))
+        shape = rs.integers(0, 3)  # random, all ones, rows all equal
+        if shape == 0:
+            se = [int(v) for v in rs.integers(0, 2, kw * kh)]
+        elif shape == 1:
+            se = [1] * (kw * kh)
+        else:
+            se = [int(v) for v in rs.integers(0, 2, kw)] * kh
         check(ops.imageDilation(x, se, kw, kh), lambda g: O.dilate(g, se, kw, kh), "dilate")
         check(ops.imageErosion(x, se, kw, kh), lambda g: O.erode(g, se, kw, kh), "erode")
+    elif which == 12:
+        k = int(rs.choice([3, 5, 7, 9, 8, 11]))
+        wt = float(rs.choice([1.0, 0.5, 1.0 / (k * k), 0.02, 2.0, 0.999, 1.0 / 3]))
+        w = [wt] * (k * k)
+        check(ops.linearFilter(x, w, k, k), lambda g: O.linear(g, w, k, k), "box linear")
+        check(ops.averageFilter(x, w, k, k), lambda g: O.average(g, w, k, k), "box average")
     elif which == 10:
         cent = rs.integers(0, 257, (B, 2)).astype(np.int32)
         got = ops.kMeansThresholding(x, torch.from_numpy(cent).cuda()).cpu().numpy()
