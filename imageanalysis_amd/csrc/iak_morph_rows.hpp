@@ -4,9 +4,10 @@
 // 8 + 2a input rows once (one 16-byte buffer load each: columns col0-4 .. col0+11, which holds
 // the +-4 columns a 9-wide element reaches), turns each into 16 bits ("this pixel counts"),
 // and an output row is the AND (erosion) or OR (dilation) of shifted row masks -- one shift
-// and one logic operation per set element for 8 outputs, or, when all rows of the element
-// are equal (boxes, horizontal lines), one horizontal pass per input row and one operation
-// per element row.  No LDS, no barrier, every input row loaded once per 8 output rows.
+// and one logic operation per set element for 8 outputs.  Elements whose rows show at most
+// three different patterns (boxes, lines, crosses, diamonds, disks) take less: one horizontal
+// pass per input row and pattern -- by doubling when the pattern is one run of ones -- and one
+// operation per element row.  No LDS, no barrier, every input row loaded once per 8 output rows.
 //   erosion (imageAnalysis.cu:421-451): out = pixel if every element's tap is non-zero, else 0;
 //     border pixels (row < a, row > H-a, col < s, col > W-s) 0.  A pixel counts if it is non-zero.
 //   dilation (imageAnalysis.cu:381-404, a scatter from every non-border foreground pixel, "255
@@ -26,10 +27,28 @@ namespace iak {
 
 struct SeRows9 {
     uint32_t m[9];  // bit j of m[i]: element (i, j) is set (dilation: already mirrored)
+    // the rows by pattern (NPAT > 0): pattern p is pat[p], used by the rows in the bit set rows_of[p];
+    // run_len[p] > 0: the pattern is run_len[p] ones from bit run_start[p] on
+    uint32_t pat[3], rows_of[3];
+    int run_start[3], run_len[3];
 };
 
-// A: half height of the element (kH = 2A + 1).  UNIFORM: all its rows are equal.
-template <bool ERODE, int A, bool UNIFORM>
+// AND (erosion) or OR (dilation) of the n bits from each position on, n >= 1, by doubling
+template <bool ERODE>
+__device__ __forceinline__ uint32_t run_of(uint32_t x, int n) {
+    uint32_t acc = x;
+    int width = 1;
+    while (2 * width <= n) {
+        acc = ERODE ? (acc & (acc >> width)) : (acc | (acc >> width));
+        width *= 2;
+    }
+    if (width < n) acc = ERODE ? (acc & (acc >> (n - width))) : (acc | (acc >> (n - width)));
+    return acc;
+}
+
+// A: half height of the element (kH = 2A + 1).  NPAT: its non-empty rows show NPAT different
+// patterns (1 to 3), or 0: element by element.
+template <bool ERODE, int A, int NPAT>
 __global__ __launch_bounds__(256) void morph_rows_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
                                                          int H, long long in_stride, long long out_stride, int s,
                                                          SeRows9 se) {
@@ -59,7 +78,9 @@ __global__ __launch_bounds__(256) void morph_rows_kernel(const uint8_t *__restri
             if (col0 == 0) prev = (1u << (4 - s + 1 > 4 ? 4 : 4 - s + 1)) - 1u;  // columns W-4+p <= W-s
             if (col0 + 8 == W) next = 0xffffu & ~((1u << (12 + s)) - 1u);     // columns p-12 >= s
         }
-        uint32_t bits[ROWS];  // bit p of row r = pixel (y0 - A + r, col0 - 4 + p) counts
+        // NPAT == 0: bit p of row r = pixel (y0 - A + r, col0 - 4 + p) counts; else per pattern: bit x = the
+        // pattern's taps around output x of that row all (erosion) / any (dilation) count
+        uint32_t bits[NPAT ? NPAT : 1][ROWS];
         uint32_t c0[8], c1[8];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
@@ -69,15 +90,20 @@ __global__ __launch_bounds__(256) void morph_rows_kernel(const uint8_t *__restri
                 const bool ok = yy >= A && yy <= H - A, okp = yy - 1 >= A && yy - 1 <= H - A, okn = yy + 1 >= A && yy + 1 <= H - A;
                 b &= (ok ? same : 0u) | (okp ? prev : 0u) | (okn ? next : 0u);
             }
-            if (UNIFORM) {
-                // the element row applied along the row: bit x+4-s... of h = all / any of its taps
-                uint32_t h = ERODE ? 0xffffffffu : 0u;
-                uint32_t m = se.m[0];
-                for (int j = 0; m != 0; j++, m >>= 1)
-                    if (m & 1u) h = ERODE ? (h & (b >> (j + base_shift))) : (h | (b >> (j + base_shift)));
-                b = h;
+            if (NPAT == 0) bits[0][r] = b;
+#pragma unroll
+            for (int p = 0; p < NPAT; p++) {
+                uint32_t h;
+                if (se.run_len[p] > 0) {  // uniform over the grid
+                    h = run_of<ERODE>(b >> (se.run_start[p] + base_shift), se.run_len[p]);
+                } else {
+                    h = ERODE ? 0xffffffffu : 0u;
+                    uint32_t m = se.pat[p];
+                    for (int j = 0; m != 0; j++, m >>= 1)
+                        if (m & 1u) h = ERODE ? (h & (b >> (j + base_shift))) : (h | (b >> (j + base_shift)));
+                }
+                bits[p][r] = h;
             }
-            bits[r] = b;
             if (ERODE && r >= A && r < A + 8) {
                 c0[r - A] = v[r][1];
                 c1[r - A] = v[r][2];
@@ -89,13 +115,14 @@ __global__ __launch_bounds__(256) void morph_rows_kernel(const uint8_t *__restri
             uint32_t acc = ERODE ? 0xffu : 0u;
 #pragma unroll
             for (int i = 0; i < KH; i++) {
-                if (UNIFORM) {
-                    acc = ERODE ? (acc & bits[r + i]) : (acc | bits[r + i]);
-                } else {
+                if (NPAT == 0) {
                     uint32_t m = se.m[i];
                     for (int j = 0; m != 0; j++, m >>= 1)
-                        if (m & 1u) acc = ERODE ? (acc & (bits[r + i] >> (j + base_shift))) : (acc | (bits[r + i] >> (j + base_shift)));
+                        if (m & 1u) acc = ERODE ? (acc & (bits[0][r + i] >> (j + base_shift))) : (acc | (bits[0][r + i] >> (j + base_shift)));
                 }
+#pragma unroll
+                for (int p = 0; p < NPAT; p++)
+                    if ((se.rows_of[p] >> i) & 1u) acc = ERODE ? (acc & bits[p][r + i]) : (acc | bits[p][r + i]);
             }
             acc &= 0xffu;
             uint32_t o0, o1;
@@ -131,21 +158,49 @@ static int launch_morph_rows(const uint8_t *in, uint8_t *out, int W, int H, int 
             const int n = erode ? i * kWe + j : (kHe - 1 - i) * kWe + (kWe - 1 - j);  // dilation gathers through the mirror image
             if (se[n] != 0) rows.m[i] |= 1u << j;
         }
-    bool uniform = true;
-    for (int i = 1; i < kHe; i++) uniform = uniform && rows.m[i] == rows.m[0];
+    // the non-empty rows by pattern
+    int npat = 0;
+    for (int p = 0; p < 3; p++) rows.pat[p] = rows.rows_of[p] = 0, rows.run_start[p] = rows.run_len[p] = 0;
+    for (int i = 0; i < kHe && npat >= 0; i++) {
+        if (rows.m[i] == 0) continue;
+        int p = 0;
+        while (p < npat && rows.pat[p] != rows.m[i]) p++;
+        if (p == npat) {
+            if (npat == 3) { npat = -1; break; }
+            rows.pat[npat++] = rows.m[i];
+        }
+        rows.rows_of[p] |= 1u << i;
+    }
+    if (npat < 0) npat = 0;  // more than three patterns: element by element
+    for (int p = 0; p < npat; p++) {
+        const uint32_t m = rows.pat[p];
+        int j0 = 0;
+        while (!((m >> j0) & 1u)) j0++;
+        int n = 0;
+        while ((m >> (j0 + n)) & 1u) n++;
+        if ((m >> (j0 + n)) == 0) rows.run_start[p] = j0, rows.run_len[p] = n;  // one run of ones
+    }
+    // (an element without any set entry has npat == 0 and no work in the element-by-element form either)
     const long long items = (long long)(W >> 3) * ((H + 7) / 8);
     const dim3 grid(blocks_x(items, 256, B, 1 << 20), B);
-#define MR_LAUNCH(E, AA, U) \
-    hipLaunchKernelGGL((morph_rows_kernel<E, AA, U>), grid, dim3(256), 0, stream, in, out, W, H, in_stride, out_stride, s, rows)
-#define MR_CASE(AA)                                                             \
-    case AA:                                                                    \
-        if (erode) { if (uniform) MR_LAUNCH(true, AA, true); else MR_LAUNCH(true, AA, false); }    \
-        else { if (uniform) MR_LAUNCH(false, AA, true); else MR_LAUNCH(false, AA, false); }       \
+#define MR_LAUNCH(E, AA, NP) \
+    hipLaunchKernelGGL((morph_rows_kernel<E, AA, NP>), grid, dim3(256), 0, stream, in, out, W, H, in_stride, out_stride, s, rows)
+#define MR_PAT(E, AA)                                  \
+    switch (npat) {                                    \
+    case 1: MR_LAUNCH(E, AA, 1); break;                \
+    case 2: MR_LAUNCH(E, AA, 2); break;                \
+    case 3: MR_LAUNCH(E, AA, 3); break;                \
+    default: MR_LAUNCH(E, AA, 0); break;               \
+    }
+#define MR_CASE(AA)                                    \
+    case AA:                                           \
+        if (erode) { MR_PAT(true, AA) } else { MR_PAT(false, AA) } \
         break;
     switch (a) {
         MR_CASE(0) MR_CASE(1) MR_CASE(2) MR_CASE(3) MR_CASE(4)
     }
 #undef MR_CASE
+#undef MR_PAT
 #undef MR_LAUNCH
     IAK_LAUNCH_CHECK();
     return 0;
