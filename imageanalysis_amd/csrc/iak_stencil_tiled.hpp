@@ -24,6 +24,10 @@ __device__ __forceinline__ uint32_t tap_at(const uint8_t *img, long long N, long
     return (idx >= 0 && idx < N) ? img[idx] : 0u;
 }
 
+}  // namespace iak
+#include "iak_linear_rows.hpp"
+namespace iak {
+
 // ---------------------------------------------------------------------------------------
 // Linear / average filter, KW x kH taps (KW odd, compile time; kH odd, run time).
 // A workgroup of 256 lanes produces a 64 x 32 tile of outputs from a (32+kH-1) x (64+KW-1)
@@ -162,6 +166,10 @@ static int launch_tiled_linear(const uint8_t *in, uint8_t *out, int W, int H, in
     for (int i = 1; i < kWe * kHe; i++) uniform = uniform && t.f[i] == t.f[0];
     if (uniform) {  // box filters whose per-tap truncation provably commutes with the sum: integer box sums
         const int rc = launch_box_sum(in, out, W, H, B, in_stride, out_stride, kWe, kHe, t.f[0], divisor, avg, s);
+        if (rc != IAK_E_UNSUPPORTED) return rc;
+    }
+    {  // square windows up to 7 x 7: in registers
+        const int rc = launch_linear_rows(in, out, W, H, B, in_stride, out_stride, kWe, kHe, divisor, avg, t, s);
         if (rc != IAK_E_UNSUPPORTED) return rc;
     }
 #define TL_CASE(K) case K: return launch_tiled_linear_kw<K>(in, out, W, H, B, in_stride, out_stride, kHe, divisor, avg, uniform, t, s);

@@ -53,6 +53,10 @@ def main():
     box11 = np.full(121, 1.0 / 121, np.float32)
     ones25f = np.ones(25, np.float32)
     ones49 = np.ones(49, np.int32)
+    b5 = np.array([1, 4, 6, 4, 1], np.float32)
+    gauss5 = (np.outer(b5, b5) / 256.0).astype(np.float32).ravel()
+    rand7 = (np.random.default_rng(3).random(49) / 25.0).astype(np.float32)
+    rand9 = (np.random.default_rng(4).random(81) / 40.0).astype(np.float32)
     ones81 = np.ones(81, np.int32)
     disk9 = np.array([1 if (i // 9 - 4) ** 2 + (i % 9 - 4) ** 2 <= 18 else 0 for i in range(81)], np.int32)
     ones81f = np.ones(81, np.float32)
@@ -89,6 +93,9 @@ def main():
         "median5": (lambda: lib.iak_median(g, o, W, H, B, N, N, ones49.ctypes.data, 5, 5, st()), 2),
         "erode5": (lambda: lib.iak_erode(g, o, W, H, B, N, N, ones49.ctypes.data, 5, 5, st()), 2),
         "dilate5": (lambda: lib.iak_dilate(g, o, W, H, B, N, N, ones49.ctypes.data, 5, 5, st()), 2),
+        "linear5_gauss": (lambda: lib.iak_linear(g, o, W, H, B, N, N, gauss5.ctypes.data, 5, 5, 0, st()), 2),
+        "linear7_rand": (lambda: lib.iak_linear(g, o, W, H, B, N, N, rand7.ctypes.data, 7, 7, 0, st()), 2),
+        "linear9_rand": (lambda: lib.iak_linear(g, o, W, H, B, N, N, rand9.ctypes.data, 9, 9, 0, st()), 2),
         "erode9": (lambda: lib.iak_erode(g, o, W, H, B, N, N, ones81.ctypes.data, 9, 9, st()), 2),
         "dilate9_disk": (lambda: lib.iak_dilate(g, o, W, H, B, N, N, disk9.ctypes.data, 9, 9, st()), 2),
         "average9": (lambda: lib.iak_linear(g, o, W, H, B, N, N, ones81f.ctypes.data, 9, 9, 1, st()), 2),
