@@ -1,7 +1,7 @@
-// Linear / average filters with square windows of 3x3 up to 7x7 and arbitrary taps, in
+// Linear / average filters with arbitrary taps and windows of up to 7 rows x 9 columns, in
 // registers.  Included by iak_stencil_tiled.hpp (Taps, is_border).
 //
-// A lane owns 8 (windows up to 5x5) or 4 (7x7: the sums of 2a+1 output rows are live at a
+// A lane owns 8 (windows up to 5 rows) or 4 (7 rows: the sums of 2a+1 output rows are live at a
 // time, and 7 x 8 of them cost too many waves) pixels x 8 rows of the output and walks
 // down the 8 + 2a input rows, one
 // 16-byte buffer load each (columns col0-4 .. col0+11), fetched four rows ahead.  (At 9x9 the
@@ -23,10 +23,10 @@
 
 namespace iak {
 
-template <bool AVG, int A, int PX>
+template <bool AVG, int A, int S, int PX>
 __global__ __launch_bounds__(256) void linear_rows_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W, int H,
                                                           long long in_stride, long long out_stride, int divisor, Taps taps) {
-    constexpr int S = A, KW = 2 * A + 1, KH = KW, ROWS = 8 + 2 * A, AHEAD = 4;
+    constexpr int KW = 2 * S + 1, KH = 2 * A + 1, ROWS = 8 + 2 * A, AHEAD = ROWS < 4 ? ROWS : 4;
     const uint8_t *src = in + (long long)blockIdx.y * in_stride;
     uint8_t *dst = out + (long long)blockIdx.y * out_stride;
     const int N = W * H;  // the launcher keeps W * (H + 16) below 2^31
@@ -91,12 +91,13 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const uint8_t *__restr
     }
 }
 
-// kW x kW taps (kW odd, 3 .. 7), already checked to keep every sum exact in float.
+// kW x kH taps (both odd, kW <= 9, kH <= 7), already checked to keep every sum exact in float.
 // IAK_E_UNSUPPORTED when this path does not apply.
 static int launch_linear_rows(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
                               int kW, int kH, int divisor, bool avg, const Taps &t, hipStream_t stream) {
-    const int a = (kH - 1) / 2;
-    if (kW != kH || (kW & 1) == 0 || a < 1 || a > 3 || W % 8 != 0 || W < 8 || (long long)W * ((long long)H + 16) >= (1LL << 31))
+    const int a = (kH - 1) / 2, s = (kW - 1) / 2;
+    if ((kW & 1) == 0 || (kH & 1) == 0 || a > 3 || s > 4 || W % 8 != 0 || W < 8 ||
+        (long long)W * ((long long)H + 16) >= (1LL << 31))
         return IAK_E_UNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(in) % 4 != 0 || reinterpret_cast<uintptr_t>(out) % 8 != 0 || in_stride % 4 != 0 ||
         out_stride % 8 != 0)
@@ -105,19 +106,30 @@ static int launch_linear_rows(const uint8_t *in, uint8_t *out, int W, int H, int
     const int px = a <= 2 ? 8 : 4;
     const long long items = (long long)(W / px) * ((H + 7) / 8);
     const dim3 grid(blocks_x(items, 256, B, 1 << 20), B);
-#define LR_CASE(AA, PX)                                                                                                            \
-    case AA:                                                                                                                   \
+#define LR_LAUNCH(AA, SS, PX)                                                                                                  \
+    do {                                                                                                                       \
         if (avg)                                                                                                               \
-            hipLaunchKernelGGL((linear_rows_kernel<true, AA, PX>), grid, dim3(256), 0, stream, in, out, W, H, in_stride, out_stride, \
-                               divisor, t);                                                                                    \
+            hipLaunchKernelGGL((linear_rows_kernel<true, AA, SS, PX>), grid, dim3(256), 0, stream, in, out, W, H, in_stride,   \
+                               out_stride, divisor, t);                                                                        \
         else                                                                                                                   \
-            hipLaunchKernelGGL((linear_rows_kernel<false, AA, PX>), grid, dim3(256), 0, stream, in, out, W, H, in_stride, out_stride, \
-                               divisor, t);                                                                                    \
+            hipLaunchKernelGGL((linear_rows_kernel<false, AA, SS, PX>), grid, dim3(256), 0, stream, in, out, W, H, in_stride,  \
+                               out_stride, divisor, t);                                                                        \
+    } while (0)
+#define LR_ROW(AA, PX)                     \
+    case AA:                               \
+        switch (s) {                       \
+        case 0: LR_LAUNCH(AA, 0, PX); break; \
+        case 1: LR_LAUNCH(AA, 1, PX); break; \
+        case 2: LR_LAUNCH(AA, 2, PX); break; \
+        case 3: LR_LAUNCH(AA, 3, PX); break; \
+        default: LR_LAUNCH(AA, 4, PX); break; \
+        }                                  \
         break;
     switch (a) {
-        LR_CASE(1, 8) LR_CASE(2, 8) LR_CASE(3, 4)
+        LR_ROW(0, 8) LR_ROW(1, 8) LR_ROW(2, 8) LR_ROW(3, 4)
     }
-#undef LR_CASE
+#undef LR_ROW
+#undef LR_LAUNCH
     IAK_LAUNCH_CHECK();
     return 0;
 }

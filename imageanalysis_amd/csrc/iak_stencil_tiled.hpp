@@ -168,7 +168,7 @@ static int launch_tiled_linear(const uint8_t *in, uint8_t *out, int W, int H, in
         const int rc = launch_box_sum(in, out, W, H, B, in_stride, out_stride, kWe, kHe, t.f[0], divisor, avg, s);
         if (rc != IAK_E_UNSUPPORTED) return rc;
     }
-    {  // square windows up to 7 x 7: in registers
+    {  // windows of up to 7 rows x 9 columns: in registers
         const int rc = launch_linear_rows(in, out, W, H, B, in_stride, out_stride, kWe, kHe, divisor, avg, t, s);
         if (rc != IAK_E_UNSUPPORTED) return rc;
     }

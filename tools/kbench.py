@@ -96,6 +96,8 @@ def main():
         "linear5_gauss": (lambda: lib.iak_linear(g, o, W, H, B, N, N, gauss5.ctypes.data, 5, 5, 0, st()), 2),
         "linear7_rand": (lambda: lib.iak_linear(g, o, W, H, B, N, N, rand7.ctypes.data, 7, 7, 0, st()), 2),
         "linear9_rand": (lambda: lib.iak_linear(g, o, W, H, B, N, N, rand9.ctypes.data, 9, 9, 0, st()), 2),
+        "linear9x1": (lambda: lib.iak_linear(g, o, W, H, B, N, N, rand9.ctypes.data, 9, 1, 0, st()), 2),
+        "linear1x7": (lambda: lib.iak_linear(g, o, W, H, B, N, N, rand9.ctypes.data, 1, 7, 0, st()), 2),
         "erode9": (lambda: lib.iak_erode(g, o, W, H, B, N, N, ones81.ctypes.data, 9, 9, st()), 2),
         "dilate9_disk": (lambda: lib.iak_dilate(g, o, W, H, B, N, N, disk9.ctypes.data, 9, 9, st()), 2),
         "average9": (lambda: lib.iak_linear(g, o, W, H, B, N, N, ones81f.ctypes.data, 9, 9, 1, st()), 2),
