@@ -26,6 +26,19 @@
 
 namespace iak {
 
+// dataset histogram: sum[v] += sum_b hist[b][v]; workgroup `block` folds images 8 block .. 8 block + 7
+#define ACC_IMAGES 8
+__device__ __forceinline__ void hist_accumulate_block(const uint32_t *__restrict__ hist, int B,
+                                                      unsigned long long *__restrict__ sum, int block) {
+    const int v = threadIdx.x;
+    const int b0 = block * ACC_IMAGES;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int i = 0; i < ACC_IMAGES; i++)
+        if (b0 + i < B) s += hist[(long long)(b0 + i) * 256 + v];
+    if (s) atomicAdd(&sum[v], s);
+}
+
 // Per image (one workgroup of 256 lanes, lane v = grey value v): walk the chain once on the
 // histogram, producing every stage's table.  tables: [B][CHAIN_MAX][256] uint16 (LUT stages
 // use the low byte).  Everything that is order-free is done across lanes; the two float
@@ -34,8 +47,16 @@ namespace iak {
 // hist_out (may be null, may be hist_in): the histogram of the run's OUTPUT, for runs made of
 // look-up stages only -- it is the input's histogram pushed through the tables, so the consumer
 // behind the run needs no counting pass.
+// Workgroups past the last image (acc_sum != nullptr) fold the data-set histogram instead, eight
+// images each: a launch of their own would cost more than the work.
 __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *hist_in, int numPixels, ChainDesc d,
-                                                         uint16_t *__restrict__ tables, uint32_t *hist_out = nullptr) {
+                                                         uint16_t *__restrict__ tables, uint32_t *hist_out = nullptr,
+                                                         int n_images = 0x7fffffff, const uint32_t *acc_hist = nullptr,
+                                                         unsigned long long *acc_sum = nullptr) {
+    if ((int)blockIdx.x >= n_images) {  // uniform over the workgroup
+        hist_accumulate_block(acc_hist, n_images, acc_sum, (int)blockIdx.x - n_images);
+        return;
+    }
     __shared__ uint32_t h[256];  // current histogram, bin 0 empty
     __shared__ uint32_t h2[256];
     __shared__ BlockScratch bs;
@@ -192,17 +213,9 @@ __global__ __launch_bounds__(HIST ? 1024 : 256) void chain_apply_kernel(const ui
     if (HIST) hist_flush(sh, hist + (long long)b * 256);
 }
 
-// dataset histogram: sum[v] += sum_b hist[b][v]; each workgroup folds 8 images
-#define ACC_IMAGES 8
 __global__ __launch_bounds__(256) void hist_accumulate_kernel(const uint32_t *__restrict__ hist, int B,
                                                               unsigned long long *__restrict__ sum) {
-    const int v = threadIdx.x;
-    const int b0 = blockIdx.x * ACC_IMAGES;
-    unsigned long long s = 0;
-#pragma unroll
-    for (int i = 0; i < ACC_IMAGES; i++)
-        if (b0 + i < B) s += hist[(long long)(b0 + i) * 256 + v];
-    if (s) atomicAdd(&sum[v], s);
+    hist_accumulate_block(hist, B, sum, blockIdx.x);
 }
 
 }  // namespace iak
@@ -881,6 +894,13 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
     const uint32_t *cur_hist = nullptr;
     uint32_t *ghist = gray_hist ? gray_hist + (size_t)b0 * 256 : sl.hist;
     if (ev) IAK_HIP(hipEventRecord(ev[0], s));
+    unsigned long long *pending_sum = nullptr;
+    auto launch_prep = [&](const ChainDesc &cd, uint32_t *hist_out) {
+        const int extra = pending_sum ? (B + ACC_IMAGES - 1) / ACC_IMAGES : 0;
+        hipLaunchKernelGGL(chain_prep_kernel, dim3(B + extra), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables, hist_out, B,
+                           (const uint32_t *)ghist, pending_sum);
+        pending_sum = nullptr;
+    };
     for (int gi = 0; gi < ng; gi++) {
         const Group &g = p->groups[gi];
         uint8_t *dst = nullptr;
@@ -901,13 +921,9 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             rc = p->input <= IAK_INPUT_AVERAGE
                      ? iak_gray_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input, s)
                      : iak_channel_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input - IAK_INPUT_RED, s);
-            if (ev) p->split[gi] = hist_sum ? 2 : 0;
-            if (rc == 0 && hist_sum) {
-                if (ev) IAK_HIP(hipEventRecord(ev[2 * gi + 1], s));
-                hipLaunchKernelGGL(hist_accumulate_kernel, dim3((B + ACC_IMAGES - 1) / ACC_IMAGES), dim3(256), 0, s, ghist, B,
-                                   hist_sum);
-                IAK_LAUNCH_CHECK();
-            }
+            if (ev) p->split[gi] = 0;
+            // the data-set histogram is folded by the next table prologue's spare workgroups, or at the end
+            pending_sum = rc == 0 ? hist_sum : nullptr;
             cur_hist = ghist;
             break;
         case G_HIST:
@@ -923,8 +939,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             if (wants && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
             // hist_from_tables: a workgroup reads its image's old histogram before it writes the new one,
             // so hist2 can be both
-            hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables,
-                               g.hist_from_tables ? sl.hist2 : (uint32_t *)nullptr);
+            launch_prep(cd, g.hist_from_tables ? sl.hist2 : (uint32_t *)nullptr);
             IAK_LAUNCH_CHECK();
             if (ev) {
                 p->split[gi] = 1;
@@ -957,7 +972,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             for (int k = 0; k < g.chain.n; k++)
                 if (g.chain.st[k].plane && g.chain.st[k].type != C_KMEANS && !aligned16(g.chain.st[k].plane))
                     return IAK_E_UNSUPPORTED;
-            hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables);
+            launch_prep(cd, nullptr);
             IAK_LAUNCH_CHECK();
             if (ev) {
                 p->split[gi] = 1;
@@ -995,7 +1010,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
                 if (wants && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
                 for (int k = 0; k < cd.n; k++)
                     if (cd.st[k].plane && cd.st[k].type != C_KMEANS && !aligned16(cd.st[k].plane)) return IAK_E_UNSUPPORTED;
-                hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables);
+                launch_prep(cd, nullptr);
                 IAK_LAUNCH_CHECK();
                 if (ev) {
                     p->split[gi] = 1;
@@ -1021,7 +1036,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             if (g.chain.n) {  // the threshold in front of the run: its table first
                 const ChainDesc cd = chain_for(p, g.chain, b0);
                 if (cd.st[0].type == C_OTSU && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
-                hipLaunchKernelGGL(chain_prep_kernel, dim3(B), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables);
+                launch_prep(cd, nullptr);
                 IAK_LAUNCH_CHECK();
                 if (ev) {
                     p->split[gi] = 1;
@@ -1064,6 +1079,10 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
         if (copy_out) IAK_HIP(hipMemcpyAsync(out, dst, (size_t)B * (size_t)N, hipMemcpyDeviceToDevice, s));
         if (dst) cur = dst;
         if (ev) IAK_HIP(hipEventRecord(ev[2 * gi + 2], s));
+    }
+    if (pending_sum) {  // no table prologue behind the grayscale pass took it along
+        hipLaunchKernelGGL(hist_accumulate_kernel, dim3((B + ACC_IMAGES - 1) / ACC_IMAGES), dim3(256), 0, s, ghist, B, pending_sum);
+        IAK_LAUNCH_CHECK();
     }
     return 0;
 }
