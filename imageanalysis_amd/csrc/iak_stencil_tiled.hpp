@@ -476,38 +476,43 @@ __global__ __launch_bounds__(CM_LANES) void column_hist_median_kernel(const uint
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     // The window's counters: byte-wise sums of word w of the kW columns lane-s .. lane+s.  They are
-    // read as NP aligned pairs of columns (8-byte LDS reads move twice the data of 4-byte ones per
-    // cycle, and an aligned pair of columns never straddles a bank pair): the pairs starting at the
-    // even column at or below lane-s cover the window and one column more, the first of them when
-    // lane-s is odd, the last one otherwise; that one is masked out of the sum.
-    constexpr int NP = (KW + 2) / 2;  // KW odd: KW + 1 columns
+    // read as (kW-1)/2 aligned pairs of columns (8-byte LDS reads move twice the data of 4-byte ones
+    // per cycle, and an aligned pair of columns never straddles a bank pair) and one single column:
+    // the window's first column when that one is odd, its last one otherwise.
+    constexpr int NP = (KW - 1) / 2;
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-    auto window_words = [&](const uint32_t *base, u32x2_t (&raw)[4][NP]) {
-#pragma unroll
-        for (int w = 0; w < 4; w++)
-#pragma unroll
-            for (int k = 0; k < NP; k++) raw[w][k] = *reinterpret_cast<const u32x2_t *>(base + w * CM_LANES + 2 * k);
+    struct Window {
+        u32x2_t pair[4][NP > 0 ? NP : 1];
+        uint32_t one[4];
     };
     const int first_col = min(max(lane - s, 0), CM_LANES - KW);  // lanes that emit nothing read a valid window too
-    const int pair0 = first_col & ~1;
-    const uint32_t keep_first = (first_col & 1) ? 0u : 0xffffffffu, keep_last = ~keep_first;
-    auto window_words2 = [&](const uint32_t *base, u32x2_t (&raw)[4][NP]) {  // two word rows only
+    const int pair0 = first_col + (first_col & 1);
+    const int single = (first_col & 1) ? first_col : first_col + KW - 1;
+    auto window_words = [&](const uint32_t *base, Window &r) {
 #pragma unroll
-        for (int w = 0; w < 2; w++)
+        for (int w = 0; w < 4; w++) {
 #pragma unroll
-            for (int k = 0; k < NP; k++) raw[w][k] = *reinterpret_cast<const u32x2_t *>(base + w * CM_LANES + 2 * k);
+            for (int k = 0; k < NP; k++) r.pair[w][k] = *reinterpret_cast<const u32x2_t *>(base + w * CM_LANES + pair0 + 2 * k);
+            r.one[w] = base[w * CM_LANES + single];
+        }
+    };
+    auto window_words2 = [&](const uint32_t *base, Window &r) {  // two word rows only
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+#pragma unroll
+            for (int k = 0; k < NP; k++) r.pair[w][k] = *reinterpret_cast<const u32x2_t *>(base + w * CM_LANES + pair0 + 2 * k);
+            r.one[w] = base[w * CM_LANES + single];
+        }
     };
     // nibble counters: even and odd nibbles are added up apart, as bytes, and interleaved again --
     // out[0..3] = the counters of values 0-3, 4-7, 8-11, 12-15 of the block, ascending
-    auto sum_nibble_words = [&](const u32x2_t (&raw)[4][NP], uint32_t (&out)[4]) {
+    auto sum_nibble_words = [&](const Window &r, uint32_t (&out)[4]) {
 #pragma unroll
         for (int w = 0; w < 2; w++) {
-            uint32_t even = 0, odd = 0;
+            uint32_t even = r.one[w] & 0x0f0f0f0fu, odd = (r.one[w] >> 4) & 0x0f0f0f0fu;
 #pragma unroll
             for (int k = 0; k < NP; k++) {
-                uint32_t x = raw[w][k].x, y = raw[w][k].y;
-                if (k == 0) x &= keep_first;
-                if (k == NP - 1) y &= keep_last;
+                const uint32_t x = r.pair[w][k].x, y = r.pair[w][k].y;
                 if (MODE == 2) {
                     const uint32_t xy = x + y;
                     even += xy & 0x0f0f0f0fu;
@@ -521,13 +526,12 @@ __global__ __launch_bounds__(CM_LANES) void column_hist_median_kernel(const uint
             out[2 * w + 1] = __builtin_amdgcn_perm(odd, even, 0x07030602u);  // values 4, 5, 6, 7
         }
     };
-    auto sum_words = [&](const u32x2_t (&raw)[4][NP], uint32_t (&out)[4]) {
+    auto sum_words = [&](const Window &r, uint32_t (&out)[4]) {
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            uint32_t sum = (raw[w][0].x & keep_first) + (NP > 1 ? raw[w][0].y : (raw[w][0].y & keep_last));
+            uint32_t sum = r.one[w];
 #pragma unroll
-            for (int k = 1; k < NP - 1; k++) sum += raw[w][k].x + raw[w][k].y;
-            if (NP > 1) sum += raw[w][NP - 1].x + (raw[w][NP - 1].y & keep_last);
+            for (int k = 0; k < NP; k++) sum += r.pair[w][k].x + r.pair[w][k].y;
             out[w] = hm_ascending(sum);
         }
     };
@@ -539,9 +543,9 @@ __global__ __launch_bounds__(CM_LANES) void column_hist_median_kernel(const uint
     // No branches inside the loop (the compiler would wait for every outstanding LDS access at
     // each of them): lanes that emit nothing read a valid window all the same and drop the result,
     // and the slide behind the strip's last row is done although nobody uses it.
-    const uint32_t *nb_blocks = block_all + pair0;
-    const uint32_t *nb_fine = fine_all + pair0;
-    u32x2_t braw[4][NP], fraw[4][NP];
+    const uint32_t *nb_blocks = block_all;
+    const uint32_t *nb_fine = fine_all;
+    Window braw, fraw;
     cm_order();
     window_words(nb_blocks, braw);
     for (int y = y0; y < y1; y++, q += W) {
