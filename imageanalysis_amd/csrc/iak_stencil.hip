@@ -16,6 +16,7 @@
 #include "iak_stencil_tiled.hpp"
 #include "iak_morph_chain.hpp"
 #include "iak_morph_rows.hpp"
+#include "iak_median25.hpp"
 
 namespace iak {
 
@@ -460,6 +461,10 @@ int iak_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long i
             op.rank = (uint32_t)(kernSum / 2);
             return launch8(in, out, W, H, B, in_stride, out_stride, op, stream);
         }
+    }
+    if (ones && kW == 5 && kH == 5) {
+        rc = launch_median25_rows(in, out, W, H, B, in_stride, out_stride, as_stream(stream));
+        if (rc != IAK_E_UNSUPPORTED) return rc;
     }
     if (ones) {
         rc = launch_column_hist_median(in, out, W, H, B, in_stride, out_stride, kW, kH, as_stream(stream));
