@@ -325,6 +325,22 @@ def test_median_sliding_histogram(ops, kW, kH, W, H, kind):
     each(lambda x: ops.medianFilter(x, w, kW, kH), lambda x: O.median(x, w, kW, kH), imgs)
 
 
+@pytest.mark.parametrize("W,H", [(8, 11), (16, 3), (24, 2), (768, 40), (64, 64), (8, 1), (40, 5)])
+@pytest.mark.parametrize("kind", ["U", "C", "K", "binary", "ramp"])
+def test_median5_network(ops, W, H, kind):
+    """The 5x5 median's comparator network (widths that are multiples of 8): one chunk wide, fewer
+    rows than the window, pixel values at both ends of the range, ties everywhere."""
+    rs = np.random.default_rng(W * 100 + H)
+    if kind == "binary":
+        imgs = (rs.integers(0, 2, (2, H, W)) * 255).astype(np.uint8)
+    elif kind == "ramp":
+        imgs = ((np.arange(2 * H * W).reshape(2, H, W) * 7) % 256).astype(np.uint8)
+    else:
+        imgs = batch(kind, W, H, 2)
+    w = [1] * 25
+    each(lambda x: ops.medianFilter(x, w, 5, 5), lambda x: O.median(x, w, 5, 5), imgs)
+
+
 @pytest.mark.parametrize("kW,kH", [(51, 5), (255, 1), (1, 255), (27, 9)])
 def test_median_wide_windows(ops, kW, kH):
     # at most 255 taps but wider than the sliding-histogram kernel's 25 columns: the bisection kernel takes them
