@@ -178,60 +178,84 @@ __device__ __forceinline__ uint32_t gray4(uint32_t r, uint32_t g, uint32_t b) {
     return o;
 }
 
-// 1024 lanes share one 32 KiB histogram table, so two workgroups (32 waves) fit a CU.
+// 1024 lanes share one 32 KiB histogram table, so two workgroups (32 waves) fit a CU -- which needs the
+// pass to stay within 64 registers per lane (waves_per_eu).  A lane's first chunk is requested before the
+// table is cleared and every further chunk before the current one is converted, so the clear, the f64
+// arithmetic and the counting all run under loads in flight; the launcher sizes the grid for about two
+// chunks per lane, so workgroups come and go and are in different phases at any time
+// (500 x 768x568: 153 us as three long-lived workgroups per image, 141 us this way; the bare
+// three-planes-in, one-plane-out traffic takes 136 us).
 #define GRAY_THREADS 1024
 template <int METHOD, bool HIST>
-__global__ __launch_bounds__(GRAY_THREADS) void gray_kernel(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ gray,
-                                                            uint32_t *__restrict__ hist, long long N,
-                                                            long long rgb_stride, long long gray_stride) {
-    __shared__ uint32_t sh[HIST ? 256 * HIST_COLS : 1];
+__global__ __launch_bounds__(GRAY_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void gray_kernel(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ gray, uint32_t *__restrict__ hist, long long N,
+                 long long rgb_stride, long long gray_stride) {
+    __shared__ __attribute__((aligned(16))) uint32_t sh[HIST ? 256 * HIST_COLS : 4];
     const int b = blockIdx.y;
     const uint8_t *R = rgb + (long long)b * rgb_stride;
     const uint8_t *G = R + N;
     const uint8_t *Bp = G + N;
     uint8_t *dst = gray + (long long)b * gray_stride;
     const int col = threadIdx.x & (HIST_COLS - 1);
-    if (HIST) hist_zero(sh);
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
-    {
-        // two chunks per iteration so that six loads are in flight per lane
-        const long long nchunks = N >> 4;
-        for (long long c = tid; c < nchunks; c += 2 * nthreads) {
-            const long long o0 = c << 4;
-            const bool two = c + nthreads < nchunks;
-            const long long o1 = two ? ((c + nthreads) << 4) : o0;
-            // METHOD 2 reads one plane only (the other two pointers may lie past the batch)
-            const u32x4 r0 = ld16<IAK_NT_GRAY_LD>(R + o0);
-            const u32x4 g0 = METHOD == 2 ? r0 : ld16<IAK_NT_GRAY_LD>(G + o0), b0 = METHOD == 2 ? r0 : ld16<IAK_NT_GRAY_LD>(Bp + o0);
-            const u32x4 r1 = ld16<IAK_NT_GRAY_LD>(R + o1);
-            const u32x4 g1 = METHOD == 2 ? r1 : ld16<IAK_NT_GRAY_LD>(G + o1), b1 = METHOD == 2 ? r1 : ld16<IAK_NT_GRAY_LD>(Bp + o1);
-            u32x4 y0, y1;
-#pragma unroll
-            for (int w = 0; w < 4; w++) y0[w] = gray4<METHOD>(r0[w], g0[w], b0[w]);
-            st16<IAK_NT_GRAY_ST>(dst + o0, y0);
-            if (HIST) {
-#pragma unroll
-                for (int w = 0; w < 4; w++) hist_add4(sh, y0[w], col);
-            }
-            if (two) {
-#pragma unroll
-                for (int w = 0; w < 4; w++) y1[w] = gray4<METHOD>(r1[w], g1[w], b1[w]);
-                st16<IAK_NT_GRAY_ST>(dst + o1, y1);
-                if (HIST) {
-#pragma unroll
-                    for (int w = 0; w < 4; w++) hist_add4(sh, y1[w], col);
-                }
-            }
+    const long long nchunks = N >> 4;
+    long long c = tid;
+    u32x4 r = {0, 0, 0, 0}, g = r, bl = r;
+    if (c < nchunks) {
+        // METHOD 2 reads one plane only (the other two pointers may lie past the batch)
+        r = ld16<IAK_NT_GRAY_LD>(R + (c << 4));
+        if (METHOD != 2) {
+            g = ld16<IAK_NT_GRAY_LD>(G + (c << 4));
+            bl = ld16<IAK_NT_GRAY_LD>(Bp + (c << 4));
         }
     }
-    const long long scalar_from = (N >> 4) << 4;
+    if (HIST) {
+        for (int i = threadIdx.x; i < 256 * HIST_COLS / 4; i += GRAY_THREADS) reinterpret_cast<u32x4 *>(sh)[i] = u32x4{0, 0, 0, 0};
+        __syncthreads();
+    }
+    while (c < nchunks) {
+        const long long cn = c + nthreads;
+        u32x4 rn = r, gn = g, bn = bl;
+        if (cn < nchunks) {
+            rn = ld16<IAK_NT_GRAY_LD>(R + (cn << 4));
+            if (METHOD != 2) {
+                gn = ld16<IAK_NT_GRAY_LD>(G + (cn << 4));
+                bn = ld16<IAK_NT_GRAY_LD>(Bp + (cn << 4));
+            }
+        }
+        u32x4 y;
+#pragma unroll
+        for (int w = 0; w < 4; w++) y[w] = gray4<METHOD>(r[w], g[w], bl[w]);
+        st16<IAK_NT_GRAY_ST>(dst + (c << 4), y);
+        if (HIST) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) hist_add4(sh, y[w], col);
+        }
+        r = rn;
+        g = gn;
+        bl = bn;
+        c = cn;
+    }
+    const long long scalar_from = nchunks << 4;
     for (long long t = scalar_from + tid; t < N; t += nthreads) {
         uint32_t y = METHOD == 2 ? R[t] : (METHOD == 0 ? lum1(R[t], G[t], Bp[t]) : avg1(R[t], G[t], Bp[t]));
         dst[t] = (uint8_t)y;
         if (HIST) atomicAdd(&sh[(y & 0xff) * HIST_COLS + col], 1u);
     }
-    if (HIST) hist_flush(sh, hist + (long long)b * 256);
+    if (HIST) {
+        // every lane takes part in the merge: four lanes per bin, eight columns each (rotated start)
+        __syncthreads();
+        constexpr int PER = GRAY_THREADS / 256, CPL = HIST_COLS / PER;
+        const int v = threadIdx.x / PER, part = threadIdx.x % PER;
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < CPL; i++) s += sh[v * HIST_COLS + ((part * CPL + i + v) & (HIST_COLS - 1))];
+#pragma unroll
+        for (int m = 1; m < PER; m <<= 1) s += __shfl_xor(s, m);
+        // value 0 is never reported (imageAnalysis.cu:136)
+        if (part == 0 && v != 0 && s != 0) atomicAdd(&hist[(long long)b * 256 + v], s);
+    }
 }
 
 // 1024 lanes per table, as the grayscale pass: 32 waves per CU instead of the 20 that five
@@ -307,23 +331,21 @@ static int gray_launch(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W,
     const long long N = (long long)W * H;
     hipStream_t s = as_stream(stream);
     dim3 block(GRAY_THREADS);
+    // about two 16-pixel chunks per lane (the second is fetched while the first is converted), but no more
+    // than 16K workgroups in the launch: beyond that every lane walks further
+    long long bx = ((N >> 4) + 2 * GRAY_THREADS - 1) / (2 * GRAY_THREADS);
+    const long long cap = (16384 + B - 1) / B;
+    if (bx > cap) bx = cap;
+    if (bx < 1) bx = 1;
+    dim3 grid((unsigned)bx, B);
     if (hist) {
         IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
-        // every workgroup pays a 32 KiB clear and a 256-atomic merge: about 1024 workgroups over the
-        // whole launch (2-4 per CU), but never less than 16K pixels each -- a single image still gets
-        // a few dozen workgroups instead of streaming through three or four
-        long long bx = (1024 + B - 1) / B;
-        const long long by_work = (N + 16383) / 16384;
-        if (bx > by_work) bx = by_work;
-        if (bx < 1) bx = 1;
-        dim3 grid((unsigned)bx, B);
 #define GH(M) hipLaunchKernelGGL((gray_kernel<M, true>), grid, block, 0, s, rgb, gray, hist, N, rgb_stride, gray_stride)
         if (method == 0) GH(0);
         else if (method == 1) GH(1);
         else GH(2);
 #undef GH
     } else {
-        dim3 grid(blocks_x((N + 31) / 32, GRAY_THREADS, B, 2048), B);
 #define GN(M) hipLaunchKernelGGL((gray_kernel<M, false>), grid, block, 0, s, rgb, gray, (uint32_t *)nullptr, N, rgb_stride, gray_stride)
         if (method == 0) GN(0);
         else if (method == 1) GN(1);
