@@ -38,6 +38,27 @@ __device__ __forceinline__ void hist_flush(const uint32_t *sh, uint32_t *hist_im
     }
 }
 
+// The same two steps for workgroups of THREADS = 512 or 1024 lanes with every lane taking part: the clear
+// as 16-byte stores, the merge with THREADS / 256 lanes per bin (a share of the columns each, rotated
+// start, partial sums added across neighbouring lanes).  sh must be 16-byte aligned.
+template <int THREADS>
+__device__ __forceinline__ void hist_zero_wide(uint32_t *sh) {
+    for (int i = threadIdx.x; i < 256 * HIST_COLS / 4; i += THREADS) reinterpret_cast<u32x4 *>(sh)[i] = u32x4{0, 0, 0, 0};
+    __syncthreads();
+}
+template <int THREADS>
+__device__ __forceinline__ void hist_flush_wide(const uint32_t *sh, uint32_t *hist_image) {
+    __syncthreads();
+    constexpr int PER = THREADS / 256, CPL = HIST_COLS / PER;
+    const int v = threadIdx.x / PER, part = threadIdx.x % PER;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < CPL; i++) s += sh[v * HIST_COLS + ((part * CPL + i + v) & (HIST_COLS - 1))];
+#pragma unroll
+    for (int m = 1; m < PER; m <<= 1) s += __shfl_xor(s, m);
+    if (part == 0 && v != 0 && s != 0) atomicAdd(&hist_image[v], s);  // value 0 is never reported (imageAnalysis.cu:136)
+}
+
 // A workgroup's 32 KiB table and its 256-atomic merge are amortised over the pixels it
 // streams: give each (1024 lanes) at least ~256K pixels, and keep the whole launch near 512
 // workgroups (two per CU) -- for a batch of 500 images that is one workgroup per image.

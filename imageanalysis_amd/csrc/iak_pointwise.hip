@@ -210,10 +210,7 @@ void gray_kernel(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ gray, ui
             bl = ld16<IAK_NT_GRAY_LD>(Bp + (c << 4));
         }
     }
-    if (HIST) {
-        for (int i = threadIdx.x; i < 256 * HIST_COLS / 4; i += GRAY_THREADS) reinterpret_cast<u32x4 *>(sh)[i] = u32x4{0, 0, 0, 0};
-        __syncthreads();
-    }
+    if (HIST) hist_zero_wide<GRAY_THREADS>(sh);
     while (c < nchunks) {
         const long long cn = c + nthreads;
         u32x4 rn = r, gn = g, bn = bl;
@@ -243,44 +240,43 @@ void gray_kernel(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ gray, ui
         dst[t] = (uint8_t)y;
         if (HIST) atomicAdd(&sh[(y & 0xff) * HIST_COLS + col], 1u);
     }
-    if (HIST) {
-        // every lane takes part in the merge: four lanes per bin, eight columns each (rotated start)
-        __syncthreads();
-        constexpr int PER = GRAY_THREADS / 256, CPL = HIST_COLS / PER;
-        const int v = threadIdx.x / PER, part = threadIdx.x % PER;
-        uint32_t s = 0;
-#pragma unroll
-        for (int i = 0; i < CPL; i++) s += sh[v * HIST_COLS + ((part * CPL + i + v) & (HIST_COLS - 1))];
-#pragma unroll
-        for (int m = 1; m < PER; m <<= 1) s += __shfl_xor(s, m);
-        // value 0 is never reported (imageAnalysis.cu:136)
-        if (part == 0 && v != 0 && s != 0) atomicAdd(&hist[(long long)b * 256 + v], s);
-    }
+    if (HIST) hist_flush_wide<GRAY_THREADS>(sh, hist + (long long)b * 256);
 }
 
 // 1024 lanes per table, as the grayscale pass: 32 waves per CU instead of the 20 that five
 // 256-lane workgroups with a table each would give, and a fifth of the tables to clear and merge.
+// HIST_UNROLL chunks per lane are in flight at any time (with one the pass is bound by memory
+// latency, 3 TB/s from HBM, not by the counting): the first set is requested before the table is
+// cleared, every further set before the current one is counted.
 #ifndef HIST_UNROLL
-#define HIST_UNROLL 4
+#define HIST_UNROLL 2
 #endif
 __global__ __launch_bounds__(GRAY_THREADS) void hist_kernel(const uint8_t *__restrict__ img, uint32_t *__restrict__ hist,
                                                    long long N, long long stride) {
-    __shared__ uint32_t sh[256 * HIST_COLS];
+    __shared__ __attribute__((aligned(16))) uint32_t sh[256 * HIST_COLS];
     const int b = blockIdx.y;
     const uint8_t *src = img + (long long)b * stride;
     const int col = threadIdx.x & (HIST_COLS - 1);
-    hist_zero(sh);
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
     const long long nchunks = N >> 4;
-    // four chunks per iteration: with one 16-byte load in flight per lane the pass is bound by
-    // memory latency (3 TB/s from HBM), not by the counting
-    for (long long c = tid; c < nchunks; c += HIST_UNROLL * nthreads) {
-        u32x4 v[HIST_UNROLL];
+    long long c = tid;
+    u32x4 v[HIST_UNROLL];
+#pragma unroll
+    for (int u = 0; u < HIST_UNROLL; u++) {
+        const long long cu = c + u * nthreads;
+        v[u] = u32x4{0, 0, 0, 0};
+        if (cu < nchunks) v[u] = ld16<true>(src + (cu << 4));
+    }
+    hist_zero_wide<GRAY_THREADS>(sh);
+    while (c < nchunks) {
+        const long long cn = c + HIST_UNROLL * nthreads;
+        u32x4 nx[HIST_UNROLL];
 #pragma unroll
         for (int u = 0; u < HIST_UNROLL; u++) {
-            const long long cu = c + u * nthreads;
-            v[u] = ld16<true>(src + ((cu < nchunks ? cu : c) << 4));
+            const long long cu = cn + u * nthreads;
+            nx[u] = v[u];
+            if (cu < nchunks) nx[u] = ld16<true>(src + (cu << 4));
         }
 #pragma unroll
         for (int u = 0; u < HIST_UNROLL; u++) {
@@ -289,10 +285,13 @@ __global__ __launch_bounds__(GRAY_THREADS) void hist_kernel(const uint8_t *__res
                 for (int w = 0; w < 4; w++) hist_add4(sh, v[u][w], col);
             }
         }
+#pragma unroll
+        for (int u = 0; u < HIST_UNROLL; u++) v[u] = nx[u];
+        c = cn;
     }
     const long long scalar_from = nchunks << 4;
     for (long long t = scalar_from + tid; t < N; t += nthreads) atomicAdd(&sh[src[t] * HIST_COLS + col], 1u);
-    hist_flush(sh, hist + (long long)b * 256);
+    hist_flush_wide<GRAY_THREADS>(sh, hist + (long long)b * 256);
 }
 
 // calcMSQE's arrayDifference (imageAnalysis.cu:780-786) and its byte sum
