@@ -149,6 +149,7 @@ WORKLOADS = {
     "P-C": (P_C, 768, 568, 500, 14, "segmentation path (gray, histogram, otsu, sobel, 3x3 dilation, 3x3 erosion, "
             "7 features per image, per-class feature statistics)"),
 }
+HIST_POOL = 64  # int64[256] rows the steps' data-set histograms take turns through (see Measurement)
 N_CLASSES = 6  # the data set's class count (imageMachineLearning.cu:212); synthetic label = image index % 6
 
 
@@ -266,9 +267,13 @@ class Measurement:
             self.labels = ((torch.arange(B, device=dev, dtype=torch.int64) + rank * B) % N_CLASSES).to(torch.int32)
             # two packed buffers (histogram + per-class count / sum / sum of squares): ONE collective per step
             self.packed = [PackedDatasetStats(N_CLASSES, dev) for _ in range(2)]
-        # Two histogram buffers: the all-reduce of one batch's sums runs on the collective's stream
-        # while the next batch is already being processed into the other buffer.
-        self.hist_bufs = [torch.zeros(256, dtype=torch.int64, device=dev) for _ in range(2)]
+        # The batch's histogram is ADDED to the buffer a step hands over, so every step needs a cleared
+        # int64[256] of its own, and the all-reduce of one batch's sums runs on the collective's stream while
+        # the next batch is already being processed into another buffer.  A fill per step is a launch per
+        # step (4.6 us for 2 KiB): the steps take turns through a pool of rows instead, cleared half a pool
+        # at a time just before that half comes round again (its reductions were waited for long before).
+        self.hist_pool = torch.zeros((HIST_POOL, 256), dtype=torch.int64, device=dev)
+        self.hist_rows = [self.hist_pool[r] for r in range(HIST_POOL)]
         self.pending = [None, None]
         self.counter = 0
 
@@ -276,18 +281,21 @@ class Measurement:
         # the batch's grayscale histogram is added to the buffer by the run; across GPUs the
         # dataset-level sums are the one exchange of the path (a few KiB, latency-bound)
         k = self.counter & 1
-        self.counter += 1
+        row = self.counter % HIST_POOL
         if self.pending[k] is not None:
             self.pending[k].wait()  # the reduction issued two steps ago: orders this stream after it, no host wait
             self.pending[k] = None
-        self.hist_bufs[k].zero_()
-        self.pipe.run(self.rgb, out=self.out, hist_sum=self.hist_bufs[k])
+        if self.counter >= HIST_POOL and row % (HIST_POOL // 2) == 0:
+            self.hist_pool[row:row + HIST_POOL // 2].zero_()
+        self.counter += 1
+        hist = self.hist_rows[row]
+        self.pipe.run(self.rgb, out=self.out, hist_sum=hist)
         if self.feats is not None:
-            self.packed[k].fill(self.hist_bufs[k], self.feats, self.labels)
+            self.packed[k].fill(hist, self.feats, self.labels)
             if self.dist is not None:
                 self.pending[k] = self.packed[k].all_reduce_async()
         elif self.dist is not None:
-            self.pending[k] = self.dist.all_reduce(self.hist_bufs[k], op=self.dist.ReduceOp.SUM, async_op=True)
+            self.pending[k] = self.dist.all_reduce(hist, op=self.dist.ReduceOp.SUM, async_op=True)
 
     def drain(self):
         for k in range(2):
@@ -487,7 +495,7 @@ def main():
                                "class_counts": [int(c) for c in count.tolist()],
                                "class_mean_area": [round(float(a), 3) for a in mean[:, 2].tolist()]}
         else:
-            line["dataset"] = {"histogram_pixels": int(m.hist_bufs[k_last].sum().item())}
+            line["dataset"] = {"histogram_pixels": int(m.hist_rows[(m.counter - 1) % HIST_POOL].sum().item())}
         if args.rehearse_on_one_gpu:
             line["rehearsal"] = "all ranks on GPU 0, gloo reduction: exercises the multi-rank code path; not a measurement"
         for k in ("pipeline_moved_bytes_per_px", "pipeline_hbm_frac_moved_bytes", "pipeline_hbm_frac_counter_traffic",

@@ -225,6 +225,9 @@ int stencil3_with_hist(const iak_op &o, const uint8_t *in, uint8_t *out, int W, 
                        long long out_stride, uint32_t *hist, void *stream);  // iak_stencil.hip
 int morph_chain3(const iak_op *ops, int n, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
                  long long out_stride, uint32_t *hist, const uint16_t *tables, void *stream);  // iak_stencil.hip
+// iak_gray_hist / iak_channel_hist (method 2) into a histogram the caller has cleared already
+int gray_hist_cleared(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B, long long rgb_stride,
+                      long long gray_stride, int method, void *stream);  // iak_pointwise.hip
 }
 
 using namespace iak;
@@ -299,6 +302,7 @@ long long op_alg_bytes(int t) {
 
 }  // namespace
 
+#define HIST_RING 8
 struct iak_pipeline {
     int W = 0, H = 0, maxB = 0, mode = 0;
     int input = IAK_INPUT_LUMINANCE;
@@ -307,7 +311,13 @@ struct iak_pipeline {
     std::vector<Group> groups;
     // device memory
     uint8_t *bufA = nullptr, *bufB = nullptr;
-    uint32_t *hist = nullptr;   // [maxB][256] grayscale histograms
+    // Grayscale histograms, [maxB][256] per run.  The counting pass adds into a cleared table, and a
+    // clear in front of every run is a launch of its own (4.5 us); so runs take turns through
+    // HIST_RING tables that one fill clears together, when the last clean one has been handed out.
+    uint32_t *hist = nullptr;       // this run's
+    uint32_t *hist_ring = nullptr;  // [HIST_RING][maxB][256]
+    int ring_next = 0, ring_clean = 0;
+    hipStream_t ring_stream = nullptr;  // the stream the tables were cleared on
     uint32_t *hist2 = nullptr;  // [maxB][256] histogram of an intermediate
     int32_t *map = nullptr;     // [maxB][256]
     int32_t *thr = nullptr;     // [maxB]
@@ -354,7 +364,7 @@ struct iak_pipeline {
 };
 
 static void free_all(iak_pipeline *p) {
-    void *ptrs[] = {p->bufA, p->bufB, p->hist, p->hist2, p->map, p->thr, p->tables, p->x0, p->x1, p->rv,
+    void *ptrs[] = {p->bufA, p->bufB, p->hist_ring, p->hist2, p->map, p->thr, p->tables, p->x0, p->x1, p->rv,
                     p->rand_state, p->kmeans_init, p->feat_ws};
     for (void *q : ptrs) (void)hipFree(q);
     for (auto &e : p->sp) (void)hipFree(e.second);
@@ -691,7 +701,8 @@ int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op
     } while (0)
     TRY(hipMalloc((void **)&p->bufA, img));
     TRY(hipMalloc((void **)&p->bufB, img));
-    TRY(hipMalloc((void **)&p->hist, sizeof(uint32_t) * 256 * (size_t)maxB));
+    TRY(hipMalloc((void **)&p->hist_ring, sizeof(uint32_t) * 256 * (size_t)maxB * HIST_RING));
+    p->hist = p->hist_ring;
     TRY(hipMalloc((void **)&p->hist2, sizeof(uint32_t) * 256 * (size_t)maxB));
     TRY(hipMalloc((void **)&p->map, sizeof(int32_t) * 256 * (size_t)maxB));
     TRY(hipMalloc((void **)&p->thr, sizeof(int32_t) * (size_t)maxB));
@@ -918,9 +929,14 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
         int rc = 0;
         switch (g.kind) {
         case G_GRAYHIST:
-            rc = p->input <= IAK_INPUT_AVERAGE
-                     ? iak_gray_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input, s)
-                     : iak_channel_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input - IAK_INPUT_RED, s);
+            if (!gray_hist)  // the executor's own table: cleared ahead of time (iak_pipeline_run)
+                rc = p->input <= IAK_INPUT_AVERAGE
+                         ? gray_hist_cleared(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input, s)
+                         : gray_hist_cleared(rgb + (long long)(p->input - IAK_INPUT_RED) * N, dst, ghist, p->W, p->H, B, 3 * N, N, 2, s);
+            else
+                rc = p->input <= IAK_INPUT_AVERAGE
+                         ? iak_gray_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input, s)
+                         : iak_channel_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input - IAK_INPUT_RED, s);
             if (ev) p->split[gi] = 0;
             // the data-set histogram is folded by the next table prologue's spare workgroups, or at the end
             pending_sum = rc == 0 ? hist_sum : nullptr;
@@ -1164,6 +1180,20 @@ int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, u
     const hipEvent_t *ev = timed ? p->ev.data() + (size_t)(p->runs_timed % p->slots) * (2 * ng + 1) : nullptr;
     const int lanes = (p->lanes > B) ? B : p->lanes;
     p->run_B = B;
+    if (!gray_hist) {
+        // Next clean histogram table.  When none is left -- or the caller has changed streams, and the
+        // order of this run after that clear is no longer given -- all of them are cleared by one fill on
+        // this stream, behind every earlier run that still reads one.
+        if (p->ring_clean == 0 || p->ring_stream != s) {
+            IAK_HIP(hipMemsetAsync(p->hist_ring, 0, sizeof(uint32_t) * 256 * (size_t)p->maxB * HIST_RING, s));
+            p->ring_clean = HIST_RING;
+            p->ring_next = 0;
+            p->ring_stream = s;
+        }
+        p->hist = p->hist_ring + (size_t)p->ring_next * 256 * (size_t)p->maxB;
+        p->ring_next++;
+        p->ring_clean--;
+    }
     if (p->n_kmeans) {  // this run's rand() draws, two per image per k-means operation, in image order
         int rc = iak_glibc_rand_centroids(p->rand_state, B, p->n_kmeans, p->kmeans_init, stream);
         if (rc) return rc;

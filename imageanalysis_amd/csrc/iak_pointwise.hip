@@ -326,7 +326,7 @@ extern "C" {
 
 // method 0 / 1: the two grayscale conversions; 2: the plane at `rgb` copied as it is
 static int gray_launch(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B, long long rgb_stride,
-                       long long gray_stride, int method, void *stream) {
+                       long long gray_stride, int method, void *stream, bool hist_cleared = false) {
     const long long N = (long long)W * H;
     hipStream_t s = as_stream(stream);
     dim3 block(GRAY_THREADS);
@@ -338,7 +338,7 @@ static int gray_launch(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W,
     if (bx < 1) bx = 1;
     dim3 grid((unsigned)bx, B);
     if (hist) {
-        IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
+        if (!hist_cleared) IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
 #define GH(M) hipLaunchKernelGGL((gray_kernel<M, true>), grid, block, 0, s, rgb, gray, hist, N, rgb_stride, gray_stride)
         if (method == 0) GH(0);
         else if (method == 1) GH(1);
@@ -453,3 +453,13 @@ int iak_gauss_noise(const uint8_t *in, uint8_t *out, long long N, int B, long lo
 }
 
 }  // extern "C"
+
+namespace iak {
+// The grayscale (method 0 / 1) or plane-copy (2, rgb pointing at the plane) pass for the executor, whose
+// histogram table has been cleared ahead of time: no clear here.
+int gray_hist_cleared(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B, long long rgb_stride,
+                      long long gray_stride, int method, void *stream) {
+    if (!rgb || !gray || !hist || W <= 0 || H <= 0 || B <= 0 || method < 0 || method > 2) return IAK_E_ARG;
+    return gray_launch(rgb, gray, hist, W, H, B, rgb_stride, gray_stride, method, stream, true);
+}
+}  // namespace iak

@@ -159,6 +159,36 @@ def test_pipeline_smaller_batch_than_planned(Pipeline):
     assert np.array_equal(full, want) and np.array_equal(part, want[:2])
 
 
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_pipeline_histogram_tables_take_turns(Pipeline, lanes):
+    """The executor's own grayscale histogram tables are cleared several at a time and handed out
+    run by run: 21 runs (more than two rounds) on alternating batches, two of them on another
+    stream, every result and the accumulated data-set histogram against the oracle."""
+    W, H, B = 64, 48, 3
+    batches = [synth.rgb_batch("C", W, H, B), synth.rgb_batch("U", W, H, B, first_index=7)]
+    x0, x1 = O.xorwow_planes(W * H)
+    want = [O.pipeline(r, P_A, x0, x1) for r in batches]
+    dev = [torch.from_numpy(r).cuda() for r in batches]
+    p = Pipeline(W, H, B, P_A, fused=True)
+    p.set_lanes(lanes)
+    hs = torch.zeros(256, dtype=torch.int64, device="cuda")
+    total = np.zeros(256, np.int64)
+    side = torch.cuda.Stream()
+    for i in range(21):
+        k = (i * 5 // 3) & 1
+        if i in (9, 10):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                got = p.run(dev[k], hist_sum=hs)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            got = p.run(dev[k], hist_sum=hs)
+        total += want[k][1]
+        assert np.array_equal(got.cpu().numpy(), want[k][0]), f"run {i}"
+    assert np.array_equal(hs.cpu().numpy(), total)
+    p.close()
+
+
 @pytest.mark.parametrize("lanes", [2, 3, 8])
 @pytest.mark.parametrize("name", ["P-A", "input.json"])
 def test_pipeline_lanes_do_not_change_results(Pipeline, lanes, name):
