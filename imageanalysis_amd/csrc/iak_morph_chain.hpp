@@ -202,10 +202,11 @@ static bool morph_chain_ok(const uint8_t *in, const uint8_t *out, int W, int H, 
 
 // tables: null, or the per-image tables whose slot 0 is the threshold in front of the run
 static int launch_morph_chain(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
-                              const MorphChainDesc &d, uint32_t *hist, const uint16_t *tables, hipStream_t s) {
+                              const MorphChainDesc &d, uint32_t *hist, const uint16_t *tables, hipStream_t s,
+                              bool hist_cleared = false) {
     if (d.n < (tables ? 1 : 2) || d.n > MC_MAX_OPS || !morph_chain_ok(in, out, W, H, in_stride, out_stride)) return IAK_E_UNSUPPORTED;
     const long long items = (long long)(W >> 3) * ((H + 7) / 8);
-    if (hist) IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
+    if (hist && !hist_cleared) IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
     bool binary = tables != nullptr;
     for (int k = 0; k < d.n; k++) binary = binary || d.dilate[k];
     const int hmode = !hist ? 0 : (binary ? 2 : 1);

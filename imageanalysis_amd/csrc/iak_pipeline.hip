@@ -222,9 +222,9 @@ __global__ __launch_bounds__(256) void hist_accumulate_kernel(const uint32_t *__
 
 namespace iak {
 int stencil3_with_hist(const iak_op &o, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
-                       long long out_stride, uint32_t *hist, void *stream);  // iak_stencil.hip
+                       long long out_stride, uint32_t *hist, void *stream, bool hist_cleared);  // iak_stencil.hip
 int morph_chain3(const iak_op *ops, int n, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
-                 long long out_stride, uint32_t *hist, const uint16_t *tables, void *stream);  // iak_stencil.hip
+                 long long out_stride, uint32_t *hist, const uint16_t *tables, void *stream, bool hist_cleared);  // iak_stencil.hip
 // iak_gray_hist / iak_channel_hist (method 2) into a histogram the caller has cleared already
 int gray_hist_cleared(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B, long long rgb_stride,
                       long long gray_stride, int method, void *stream);  // iak_pointwise.hip
@@ -314,11 +314,14 @@ struct iak_pipeline {
     // Grayscale histograms, [maxB][256] per run.  The counting pass adds into a cleared table, and a
     // clear in front of every run is a launch of its own (4.5 us); so runs take turns through
     // HIST_RING tables that one fill clears together, when the last clean one has been handed out.
+    // The table for an intermediate's histogram (hist2) comes from the same ring: its first user in a run
+    // finds it clear.
     uint32_t *hist = nullptr;       // this run's
-    uint32_t *hist_ring = nullptr;  // [HIST_RING][maxB][256]
+    uint32_t *hist_ring = nullptr;  // [HIST_RING][2][maxB][256]
+    bool hist2_clear = false;       // hist2 has not been written in this run
     int ring_next = 0, ring_clean = 0;
     hipStream_t ring_stream = nullptr;  // the stream the tables were cleared on
-    uint32_t *hist2 = nullptr;  // [maxB][256] histogram of an intermediate
+    uint32_t *hist2 = nullptr;  // [maxB][256] histogram of an intermediate (this run's)
     int32_t *map = nullptr;     // [maxB][256]
     int32_t *thr = nullptr;     // [maxB]
     uint16_t *tables = nullptr; // [maxB][CHAIN_MAX][256]
@@ -364,7 +367,7 @@ struct iak_pipeline {
 };
 
 static void free_all(iak_pipeline *p) {
-    void *ptrs[] = {p->bufA, p->bufB, p->hist_ring, p->hist2, p->map, p->thr, p->tables, p->x0, p->x1, p->rv,
+    void *ptrs[] = {p->bufA, p->bufB, p->hist_ring, p->map, p->thr, p->tables, p->x0, p->x1, p->rv,
                     p->rand_state, p->kmeans_init, p->feat_ws};
     for (void *q : ptrs) (void)hipFree(q);
     for (auto &e : p->sp) (void)hipFree(e.second);
@@ -701,9 +704,9 @@ int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op
     } while (0)
     TRY(hipMalloc((void **)&p->bufA, img));
     TRY(hipMalloc((void **)&p->bufB, img));
-    TRY(hipMalloc((void **)&p->hist_ring, sizeof(uint32_t) * 256 * (size_t)maxB * HIST_RING));
+    TRY(hipMalloc((void **)&p->hist_ring, sizeof(uint32_t) * 256 * (size_t)maxB * 2 * HIST_RING));
     p->hist = p->hist_ring;
-    TRY(hipMalloc((void **)&p->hist2, sizeof(uint32_t) * 256 * (size_t)maxB));
+    p->hist2 = p->hist_ring + 256 * (size_t)maxB;
     TRY(hipMalloc((void **)&p->map, sizeof(int32_t) * 256 * (size_t)maxB));
     TRY(hipMalloc((void **)&p->thr, sizeof(int32_t) * (size_t)maxB));
     TRY(hipMalloc((void **)&p->tables, sizeof(uint16_t) * 256 * CHAIN_MAX * (size_t)maxB));
@@ -906,6 +909,13 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
     uint32_t *ghist = gray_hist ? gray_hist + (size_t)b0 * 256 : sl.hist;
     if (ev) IAK_HIP(hipEventRecord(ev[0], s));
     unsigned long long *pending_sum = nullptr;
+    // hist2 of this slice is still as the ring's fill left it: its first writer need not clear it
+    bool hist2_clear = p->hist2_clear;
+    auto take_hist2 = [&]() {
+        const bool was = hist2_clear;
+        hist2_clear = false;
+        return was;
+    };
     auto launch_prep = [&](const ChainDesc &cd, uint32_t *hist_out) {
         const int extra = pending_sum ? (B + ACC_IMAGES - 1) / ACC_IMAGES : 0;
         hipLaunchKernelGGL(chain_prep_kernel, dim3(B + extra), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables, hist_out, B,
@@ -944,6 +954,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             break;
         case G_HIST:
             rc = iak_hist(cur, sl.hist2, N, B, N, s);
+            hist2_clear = false;
             cur_hist = sl.hist2;
             break;
         case G_CHAIN: {
@@ -956,6 +967,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             // hist_from_tables: a workgroup reads its image's old histogram before it writes the new one,
             // so hist2 can be both
             launch_prep(cd, g.hist_from_tables ? sl.hist2 : (uint32_t *)nullptr);
+            if (g.hist_from_tables) hist2_clear = false;
             IAK_LAUNCH_CHECK();
             if (ev) {
                 p->split[gi] = 1;
@@ -964,7 +976,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             if (g.emit_hist) {
                 // few, large workgroups: each pays a 32 KiB table and a 256-atomic merge.  The table
                 // prologue above has consumed the old histogram (stream order), so hist2 can be reused.
-                IAK_HIP(hipMemsetAsync(sl.hist2, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
+                if (!take_hist2()) IAK_HIP(hipMemsetAsync(sl.hist2, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
                 dim3 grid(blocks_x((N + 31) / 32, 1024, B, 1024), B);
                 hipLaunchKernelGGL((chain_apply_kernel<true>), grid, dim3(1024), 0, s, cur, dst, N, N, N, cd, sl.tables, sl.hist2);
                 IAK_LAUNCH_CHECK();
@@ -1060,7 +1072,8 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
                 }
                 thr_tables = sl.tables;
             }
-            rc = morph_chain3(run, g.n_ops, cur, dst, p->W, p->H, B, N, N, g.emit_hist ? sl.hist2 : nullptr, thr_tables, s);
+            rc = morph_chain3(run, g.n_ops, cur, dst, p->W, p->H, B, N, N, g.emit_hist ? sl.hist2 : nullptr, thr_tables, s,
+                              g.emit_hist ? take_hist2() : false);
             if (rc == IAK_E_UNSUPPORTED && !thr_tables && dst != sl.bufA && dst != sl.bufB && (cur == sl.bufA || cur == sl.bufB)) {
                 // the caller's output buffer is not aligned for the one-pass kernel: one operation
                 // at a time through the two intermediate buffers
@@ -1069,6 +1082,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
                 for (int k = 0; k < g.n_ops && rc == 0; k++) {
                     uint8_t *to = (k == g.n_ops - 1) ? dst : (from == sl.bufA ? sl.bufB : sl.bufA);
                     rc = run_single_op(p, sl, run[k], from, to, B, nullptr, s);
+                    hist2_clear = false;
                     from = to;
                 }
                 if (rc == 0 && g.emit_hist) rc = iak_hist(dst, sl.hist2, N, B, N, s);
@@ -1078,7 +1092,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
         }
         case G_OP:
             if (g.emit_hist) {
-                rc = stencil3_with_hist(p->ops[g.op_index].op, cur, dst, p->W, p->H, B, N, N, sl.hist2, s);
+                rc = stencil3_with_hist(p->ops[g.op_index].op, cur, dst, p->W, p->H, B, N, N, sl.hist2, s, take_hist2());
                 if (rc == IAK_E_UNSUPPORTED) {  // buffers not aligned for the 8-pixel path: two passes
                     rc = run_single_op(p, sl, p->ops[g.op_index].op, cur, dst, B, nullptr, s);
                     if (rc == 0) rc = iak_hist(dst, sl.hist2, N, B, N, s);
@@ -1088,6 +1102,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             }
             rc = run_single_op(p, sl, p->ops[g.op_index].op, cur, dst, B,
                                kmeans_of(p, p->ops[g.op_index].kmeans_index, b0), s);
+            hist2_clear = false;  // some operations count into it
             cur_hist = nullptr;
             break;
         }
@@ -1185,15 +1200,17 @@ int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B, u
         // order of this run after that clear is no longer given -- all of them are cleared by one fill on
         // this stream, behind every earlier run that still reads one.
         if (p->ring_clean == 0 || p->ring_stream != s) {
-            IAK_HIP(hipMemsetAsync(p->hist_ring, 0, sizeof(uint32_t) * 256 * (size_t)p->maxB * HIST_RING, s));
+            IAK_HIP(hipMemsetAsync(p->hist_ring, 0, sizeof(uint32_t) * 256 * (size_t)p->maxB * 2 * HIST_RING, s));
             p->ring_clean = HIST_RING;
             p->ring_next = 0;
             p->ring_stream = s;
         }
-        p->hist = p->hist_ring + (size_t)p->ring_next * 256 * (size_t)p->maxB;
+        p->hist = p->hist_ring + (size_t)p->ring_next * 2 * 256 * (size_t)p->maxB;
+        p->hist2 = p->hist + 256 * (size_t)p->maxB;
         p->ring_next++;
         p->ring_clean--;
     }
+    p->hist2_clear = !gray_hist;
     if (p->n_kmeans) {  // this run's rand() draws, two per image per k-means operation, in image order
         int rc = iak_glibc_rand_centroids(p->rand_state, B, p->n_kmeans, p->kmeans_init, stream);
         if (rc) return rc;

@@ -313,11 +313,11 @@ static bool aligned8_ok(const uint8_t *in, const uint8_t *out, int W, long long 
 // table and a 256-atomic merge)
 template <class Op>
 static int launch8(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
-                   const Op &op, void *stream, uint32_t *hist = nullptr) {
+                   const Op &op, void *stream, uint32_t *hist = nullptr, bool hist_cleared = false) {
     hipStream_t s = as_stream(stream);
     const bool anyw = !aligned8_ok(in, out, W, in_stride, out_stride);
     const long long items = (long long)((W + 7) >> 3) * ((H + 7) / 8);
-    if (hist) IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
+    if (hist && !hist_cleared) IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
     const dim3 grid(blocks_x(items, 256, B, hist ? 4096 : 1 << 20), B);
 #define IAK_LAUNCH8(HIST, ANYW)                                                                                       \
     hipLaunchKernelGGL((stencil8_kernel<Op, 8, HIST, ANYW>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, \
@@ -347,10 +347,10 @@ static dim3 generic_grid(int W, int H, int B) { return dim3(blocks_x((long long)
 // executor (not part of the C ABI).  IAK_E_UNSUPPORTED when the operation or the buffers do not
 // qualify; the caller then runs the operation and a histogram pass separately.
 int stencil3_with_hist(const iak_op &o, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
-                       long long out_stride, uint32_t *hist, void *stream) {
+                       long long out_stride, uint32_t *hist, void *stream, bool hist_cleared) {
     if (check_image_args(in, out, W, H, B, in_stride, out_stride) || !hist) return IAK_E_ARG;
     if (!fast8_ok(in, out, W, H, in_stride, out_stride)) return IAK_E_UNSUPPORTED;
-    auto go = [&](const auto &op) { return launch8(in, out, W, H, B, in_stride, out_stride, op, stream, hist); };
+    auto go = [&](const auto &op) { return launch8(in, out, W, H, B, in_stride, out_stride, op, stream, hist, hist_cleared); };
     switch (o.type) {
     case IAK_OP_LINEAR:
         if (o.kW != 3 || o.kH != 3) return IAK_E_UNSUPPORTED;
@@ -385,7 +385,7 @@ int stencil3_with_hist(const iak_op &o, const uint8_t *in, uint8_t *out, int W, 
 // each image's tables = the threshold's table).  hist may be null.  IAK_E_UNSUPPORTED when the
 // run or the buffers do not qualify.
 int morph_chain3(const iak_op *ops, int n, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
-                 long long out_stride, uint32_t *hist, const uint16_t *tables, void *stream) {
+                 long long out_stride, uint32_t *hist, const uint16_t *tables, void *stream, bool hist_cleared) {
     if (check_image_args(in, out, W, H, B, in_stride, out_stride)) return IAK_E_ARG;
     if (n < (tables ? 1 : 2) || n > MC_MAX_OPS) return IAK_E_UNSUPPORTED;
     MorphChainDesc d;
@@ -397,7 +397,7 @@ int morph_chain3(const iak_op *ops, int n, const uint8_t *in, uint8_t *out, int 
         d.mask[k] = se_mask3(o.ikernel);
         d.dilate[k] = o.type == IAK_OP_DILATE;
     }
-    return launch_morph_chain(in, out, W, H, B, in_stride, out_stride, d, hist, tables, as_stream(stream));
+    return launch_morph_chain(in, out, W, H, B, in_stride, out_stride, d, hist, tables, as_stream(stream), hist_cleared);
 }
 
 }  // namespace iak

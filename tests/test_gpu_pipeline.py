@@ -160,16 +160,20 @@ def test_pipeline_smaller_batch_than_planned(Pipeline):
 
 
 @pytest.mark.parametrize("lanes", [1, 2])
-def test_pipeline_histogram_tables_take_turns(Pipeline, lanes):
-    """The executor's own grayscale histogram tables are cleared several at a time and handed out
-    run by run: 21 runs (more than two rounds) on alternating batches, two of them on another
-    stream, every result and the accumulated data-set histogram against the oracle."""
+@pytest.mark.parametrize("name", ["P-A", "P-C", "lut-run", "noise-then-stats", "otsu+dilate+erode", "eq+sobel"])
+def test_pipeline_histogram_tables_take_turns(Pipeline, lanes, name):
+    """The executor's own histogram tables (grayscale image, intermediates) are cleared several at
+    a time and handed out run by run: 21 runs (more than two rounds) on alternating batches, two
+    of them on another stream, one with the caller's own grayscale histogram array; every result
+    and the accumulated data-set histogram against the oracle."""
     W, H, B = 64, 48, 3
+    ops = CHAINS[name]
     batches = [synth.rgb_batch("C", W, H, B), synth.rgb_batch("U", W, H, B, first_index=7)]
     x0, x1 = O.xorwow_planes(W * H)
-    want = [O.pipeline(r, P_A, x0, x1) for r in batches]
+    want = [O.pipeline(r, ops, x0, x1) for r in batches]
     dev = [torch.from_numpy(r).cuda() for r in batches]
-    p = Pipeline(W, H, B, P_A, fused=True)
+    gh = torch.empty((B, 256), dtype=torch.int32, device="cuda")
+    p = Pipeline(W, H, B, ops, fused=True)
     p.set_lanes(lanes)
     hs = torch.zeros(256, dtype=torch.int64, device="cuda")
     total = np.zeros(256, np.int64)
@@ -181,6 +185,10 @@ def test_pipeline_histogram_tables_take_turns(Pipeline, lanes):
             with torch.cuda.stream(side):
                 got = p.run(dev[k], hist_sum=hs)
             torch.cuda.current_stream().wait_stream(side)
+        elif i == 5:
+            got = p.run(dev[k], hist_sum=hs, gray_hist=gh)
+            for b in range(B):
+                assert np.array_equal(gh[b].cpu().numpy(), O.hist(O.gray(batches[k][b], 0)))
         else:
             got = p.run(dev[k], hist_sum=hs)
         total += want[k][1]
