@@ -300,7 +300,11 @@ int iak_pipeline_set_input(iak_pipeline *p, int input);
  * rgb and out may have any alignment.  The fused passes work on 16-byte aligned images; when
  * `out` is not (W % 16 == 0 plans), the last pass writes the executor's own buffer and one
  * device-to-device copy to `out` follows -- allocations of hipMalloc / torch are aligned and
- * never pay it. */
+ * never pay it.
+ * Runs of one pipeline are expected on one stream, or on streams ordered after one another (as
+ * any use of its buffers requires): the executor's histogram tables are cleared eight runs'
+ * worth at a time on the stream of the run that finds none clean, and a run on a different
+ * stream than the previous one clears them again there. */
 int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B,
                      unsigned long long *hist_sum, uint32_t *gray_hist, void *stream);
 /* Cuts every batch into `lanes` (1..8) consecutive sub-batches that run concurrently on
