@@ -3,8 +3,9 @@
 equalise -> Gaussian noise -> salt-and-pepper -> 3x3 linear -> 3x3 median -> Sobel) on a
 device-resident batch of synthetic 768x568 cell-like images, through the C ABI's batched
 executor.  One process per GPU; images shard image-wise (every rank owns a full batch,
-weak scaling); the only collective is one all-reduce of the dataset-level sums per step
-(the 256-bin histogram; with feature extraction also the per-class feature statistics).
+weak scaling); the only collective is the all-reduce of the dataset-level sums of every step
+(the 256-bin histogram; with feature extraction also the per-class feature statistics), the
+rows of --reduce-every consecutive steps travelling together.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -41,6 +42,9 @@ def parse_args(argv=None):
     ap.add_argument("--settle-ms", type=float, default=100.0,
                     help="run the pipeline untimed for this long before the warm-up steps (clock ramp after the idle "
                          "gap of input generation); 0 disables")
+    ap.add_argument("--reduce-every", type=int, default=8, choices=[1, 2, 4, 8, 16, 32],
+                    help="steps whose data-set sums travel in one all-reduce (each step's sums keep a row of their own; "
+                         "the collective is latency-bound, so fewer, larger ones cost less per step)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the all-reduce path even with one rank (self-test of the multi-GPU path)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -260,48 +264,67 @@ class Measurement:
         self.pipe = Pipeline(W, H, B, ops, fused=mode)
         self.pipe.set_lanes(args.lanes)
         self.feats = None
+        self.reduce_every = args.reduce_every
+        # The batch's histogram is ADDED to the buffer a step hands over, so every step needs a cleared
+        # int64[256] of its own.  A fill per step is a launch per step (4.6 us for 2 KiB): the steps take
+        # turns through a pool of rows instead, cleared half a pool at a time just before that half comes
+        # round again.  Rows also let ONE collective carry the sums of several steps: the all-reduce of a
+        # few KiB is latency-bound (and costs the stream two cross-stream waits), so the rows of
+        # `reduce_every` consecutive steps are reduced together, asynchronously, while later batches are
+        # processed into other rows.
+        self.hist_pool = torch.zeros((HIST_POOL, 256), dtype=torch.int64, device=dev)
+        self.hist_rows = [self.hist_pool[r] for r in range(HIST_POOL)]
         if any(o["type"] == OP_FEATURES for o in ops):
             from imageanalysis_amd.dist import PackedDatasetStats
             self.feats = torch.zeros((B, 7), dtype=torch.float32, device=dev)
             self.pipe.bind_features(self.feats)
             self.labels = ((torch.arange(B, device=dev, dtype=torch.int64) + rank * B) % N_CLASSES).to(torch.int32)
-            # two packed buffers (histogram + per-class count / sum / sum of squares): ONE collective per step
-            self.packed = [PackedDatasetStats(N_CLASSES, dev) for _ in range(2)]
-        # The batch's histogram is ADDED to the buffer a step hands over, so every step needs a cleared
-        # int64[256] of its own, and the all-reduce of one batch's sums runs on the collective's stream while
-        # the next batch is already being processed into another buffer.  A fill per step is a launch per
-        # step (4.6 us for 2 KiB): the steps take turns through a pool of rows instead, cleared half a pool
-        # at a time just before that half comes round again (its reductions were waited for long before).
-        self.hist_pool = torch.zeros((HIST_POOL, 256), dtype=torch.int64, device=dev)
-        self.hist_rows = [self.hist_pool[r] for r in range(HIST_POOL)]
-        self.pending = [None, None]
+            # histogram + per-class count / sum / sum of squares of a step packed into one row
+            self.packed_pool = torch.zeros((HIST_POOL, PackedDatasetStats.length(N_CLASSES)), dtype=torch.float64, device=dev)
+            self.packed = [PackedDatasetStats(N_CLASSES, dev, buf=self.packed_pool[r]) for r in range(HIST_POOL)]
+        self.pending = []       # collectives in flight, oldest first
+        self.bucket_start = 0   # first row of the steps not handed to a collective yet
+        self.bucket_rows = 0
         self.counter = 0
 
+    def _reduce_bucket(self):
+        """One asynchronous all-reduce over the rows of the steps since the last one."""
+        if self.dist is None or self.bucket_rows == 0:
+            self.bucket_rows = 0
+            return
+        pool = self.packed_pool if self.feats is not None else self.hist_pool
+        rows = pool[self.bucket_start:self.bucket_start + self.bucket_rows]
+        self.pending.append(self.dist.all_reduce(rows, op=self.dist.ReduceOp.SUM, async_op=True))
+        self.bucket_rows = 0
+        while len(self.pending) > 2:
+            self.pending.pop(0).wait()  # orders this stream after that collective; no host wait
+
     def step(self):
-        # the batch's grayscale histogram is added to the buffer by the run; across GPUs the
+        # the batch's grayscale histogram is added to this step's row by the run; across GPUs the
         # dataset-level sums are the one exchange of the path (a few KiB, latency-bound)
-        k = self.counter & 1
         row = self.counter % HIST_POOL
-        if self.pending[k] is not None:
-            self.pending[k].wait()  # the reduction issued two steps ago: orders this stream after it, no host wait
-            self.pending[k] = None
         if self.counter >= HIST_POOL and row % (HIST_POOL // 2) == 0:
+            # this half comes round again: its collectives were issued at least half a pool ago
+            for w in self.pending[:-1]:
+                w.wait()
+            del self.pending[:-1]
             self.hist_pool[row:row + HIST_POOL // 2].zero_()
         self.counter += 1
         hist = self.hist_rows[row]
         self.pipe.run(self.rgb, out=self.out, hist_sum=hist)
         if self.feats is not None:
-            self.packed[k].fill(hist, self.feats, self.labels)
-            if self.dist is not None:
-                self.pending[k] = self.packed[k].all_reduce_async()
-        elif self.dist is not None:
-            self.pending[k] = self.dist.all_reduce(hist, op=self.dist.ReduceOp.SUM, async_op=True)
+            self.packed[row].fill(hist, self.feats, self.labels)
+        if self.bucket_rows == 0:
+            self.bucket_start = row
+        self.bucket_rows += 1
+        if (row + 1) % self.reduce_every == 0:  # buckets end on multiples of reduce_every: never across the pool's end
+            self._reduce_bucket()
 
     def drain(self):
-        for k in range(2):
-            if self.pending[k] is not None:
-                self.pending[k].wait()
-                self.pending[k] = None
+        self._reduce_bucket()
+        for w in self.pending:
+            w.wait()
+        self.pending = []
 
     def run(self, steps, warmup, settle_ms, events=True):
         if settle_ms > 0:
@@ -485,10 +508,11 @@ def main():
                        "images_per_gpu": B, "settle_ms": args.settle_ms,
                        "mode": "stagewise" if args.stagewise else ("fused-pointwise" if args.pointwise else ("fused-strips" if args.strips else "fused")),
                        "lanes": args.lanes,
-                       "parallelism": f"image-wise shards x{world}, one all-reduce of the {reduction} per step"},
+                       "parallelism": f"image-wise shards x{world}, the {reduction} of every step all-reduced, "
+                                      f"{args.reduce_every} steps' rows per collective"},
         }
         # what the last step's reduction left: the dataset-level sums over all ranks
-        k_last = (m.counter - 1) & 1
+        k_last = (m.counter - 1) % HIST_POOL
         if m.feats is not None:
             count, mean, _ = m.packed[k_last].class_stats()
             line["dataset"] = {"histogram_pixels": int(m.packed[k_last].histogram().sum().item()),

@@ -70,9 +70,18 @@ class PackedDatasetStats:
     float64.  Every integer in it stays far below 2^53 (10,000 images of 768x568 are 4.4e9
     pixels), so the integer parts are summed exactly whatever the number of ranks."""
 
-    def __init__(self, n_classes, device):
+    @staticmethod
+    def length(n_classes):
+        return 256 + int(n_classes) * (1 + 2 * N_FEATURES)
+
+    def __init__(self, n_classes, device, buf=None):
+        """buf: a float64 array of length(n_classes) to use instead of an own one -- e.g. a row of a
+        2-D array, so that one collective over several rows carries several batches' sums."""
         self.C = int(n_classes)
-        self.buf = torch.zeros(256 + self.C * (1 + 2 * N_FEATURES), dtype=torch.float64, device=device)
+        if buf is None:
+            buf = torch.zeros(self.length(n_classes), dtype=torch.float64, device=device)
+        assert buf.dtype == torch.float64 and buf.is_contiguous() and buf.numel() == self.length(n_classes)
+        self.buf = buf
         c, f = self.C, N_FEATURES
         self.hist = self.buf[:256]
         self.count = self.buf[256:256 + c]
