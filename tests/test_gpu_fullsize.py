@@ -110,3 +110,39 @@ def test_config4_4096_square_large_windows(mods):
     # re-running reproduces it
     assert not np.array_equal(got[1], got[0])
     assert np.array_equal(p.run(both).cpu().numpy(), got)
+
+
+def test_grayscale_pass_when_lanes_walk_more_than_two_chunks(mods):
+    """A launch is capped at 16K workgroups; past that every lane of the grayscale pass walks further
+    than the two chunks it is sized for.  3000 images of 768x284 (lanes take up to three chunks, the
+    last pixels of each image fall to the scalar tail: 768*284 + 5 per image would not be a whole image,
+    so the odd tail comes from a second call on 37x29 images): every pixel against the same float64
+    expression evaluated by torch on the device (one rounding per operation, as the reference's), the
+    per-image histograms against a count of the result."""
+    ops, _ = mods
+    from imageanalysis_amd import lib as L
+    lib = L.load()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(99)
+    for (W, H, B) in [(768, 284, 3000), (37, 29, 2000)]:
+        N = W * H
+        rgb = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, device="cuda", generator=g)
+        gray = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")
+        hist = torch.empty((B, 256), dtype=torch.int32, device="cuda")
+        L.check(lib.iak_gray_hist(rgb.data_ptr(), gray.data_ptr(), hist.data_ptr(), W, H, B, 3 * N, N, 0,
+                                  torch.cuda.current_stream().cuda_stream), "iak_gray_hist")
+        want = torch.empty_like(gray)
+        for s in range(0, B, 500):
+            r, gg, b = (rgb[s:s + 500, c].to(torch.float64) for c in range(3))
+            want[s:s + 500] = ((0.21 * r + 0.72 * gg) + 0.07 * b).to(torch.int32).to(torch.uint8)
+        assert torch.equal(gray, want)
+        # histogram of image b = counts of its non-zero values
+        flat = want.view(B, N).to(torch.int64) + 256 * torch.arange(B, device="cuda").view(B, 1)
+        counts = torch.bincount(flat.view(-1), minlength=256 * B).view(B, 256)
+        counts[:, 0] = 0
+        assert torch.equal(hist.to(torch.int64), counts)
+        # and the oracle on three of the images
+        for i in (0, B // 2, B - 1):
+            assert np.array_equal(gray[i].cpu().numpy(), O.gray(rgb[i].cpu().numpy(), 0))
+        del rgb, gray, hist, want, flat, counts
+        torch.cuda.empty_cache()
