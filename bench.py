@@ -508,8 +508,9 @@ def main():
                        "images_per_gpu": B, "settle_ms": args.settle_ms,
                        "mode": "stagewise" if args.stagewise else ("fused-pointwise" if args.pointwise else ("fused-strips" if args.strips else "fused")),
                        "lanes": args.lanes,
-                       "parallelism": f"image-wise shards x{world}, the {reduction} of every step all-reduced, "
-                                      f"{args.reduce_every} steps' rows per collective"},
+                       "parallelism": (f"image-wise shards x{world}, the {reduction} of every step all-reduced, "
+                                       f"{args.reduce_every} steps' rows per collective" if m.dist is not None else
+                                       f"one GPU: the {reduction} of every step stays on this GPU (no collective)")},
         }
         # what the last step's reduction left: the dataset-level sums over all ranks
         k_last = (m.counter - 1) % HIST_POOL
