@@ -50,6 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks that all use GPU 0 and reduce over gloo: exercises the launch, sharding and reduction "
                          "code on a one-GPU machine.  The line it prints is marked as a rehearsal, not a measurement")
+    ap.add_argument("--hang-dump-s", type=float, default=0.0,
+                    help="debugging aid: write every thread's Python stack to stderr if the run is still going after "
+                         "this many seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="default P-A run only: skip the short P-B / P-C / configuration-kernel measurements")
@@ -283,6 +286,7 @@ class Measurement:
             self.packed_pool = torch.zeros((HIST_POOL, PackedDatasetStats.length(N_CLASSES)), dtype=torch.float64, device=dev)
             self.packed = [PackedDatasetStats(N_CLASSES, dev, buf=self.packed_pool[r]) for r in range(HIST_POOL)]
         self.pending = []       # collectives in flight, oldest first
+        self.via_host = bool(args.rehearse_on_one_gpu)
         self.bucket_start = 0   # first row of the steps not handed to a collective yet
         self.bucket_rows = 0
         self.counter = 0
@@ -294,10 +298,19 @@ class Measurement:
             return
         pool = self.packed_pool if self.feats is not None else self.hist_pool
         rows = pool[self.bucket_start:self.bucket_start + self.bucket_rows]
-        self.pending.append(self.dist.all_reduce(rows, op=self.dist.ReduceOp.SUM, async_op=True))
         self.bucket_rows = 0
-        while len(self.pending) > 2:
-            self.pending.pop(0).wait()  # orders this stream after that collective; no host wait
+        if self.via_host:
+            # The gloo rehearsal reduces a host copy, synchronously: gloo's collectives on device tensors,
+            # issued asynchronously between kernel launches, were seen to stall for good on a shared GPU.
+            host = rows.cpu()
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM)
+            rows.copy_(host)
+            return
+        # At most two collectives in flight (wait() orders this stream after the collective without
+        # blocking the host).
+        while len(self.pending) >= 2:
+            self.pending.pop(0).wait()
+        self.pending.append(self.dist.all_reduce(rows, op=self.dist.ReduceOp.SUM, async_op=True))
 
     def step(self):
         # the batch's grayscale histogram is added to this step's row by the run; across GPUs the
@@ -327,7 +340,7 @@ class Measurement:
         self.pending = []
 
     def run(self, steps, warmup, settle_ms, events=True):
-        if settle_ms > 0:
+        if settle_ms > 0 and self.dist is None:
             # The GPU has been idle or running small torch kernels while the inputs were made; its clocks take
             # some tens of milliseconds of load to come back up.  Untimed, like the warm-up steps.
             t_end = time.perf_counter() + settle_ms * 1e-3
@@ -335,6 +348,20 @@ class Measurement:
                 for _ in range(10):
                     self.step()
                 torch.cuda.synchronize()
+        elif settle_ms > 0:
+            # The same with several ranks, by COUNT: steps issue collectives, so every rank has to run the
+            # same number of them -- ten steps are timed and the slowest rank's estimate decides how many follow.
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                self.step()
+            torch.cuda.synchronize()
+            per_step = max((time.perf_counter() - t0) / 10, 1e-6)
+            more = torch.tensor([int(settle_ms * 1e-3 / per_step)], dtype=torch.int64, device=self.dev)
+            self.dist.all_reduce(more, op=self.dist.ReduceOp.MIN)
+            for _ in range(min(int(more.item()), 2000)):
+                self.step()
+            torch.cuda.synchronize()
         for _ in range(warmup):
             self.step()
         # per-kernel HIP events on a sample of the timed steps (every 8th, at least one): each timed
@@ -470,6 +497,9 @@ def side_measurement(args, name, ops, B, dev, variant, steps, cpu_seconds):
 
 def main():
     args = parse_args()
+    if args.hang_dump_s > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.hang_dump_s, exit=False, file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -70,6 +70,17 @@ def test_bench_starts_its_own_ranks():
     assert abs(line["value"] - 2 * 12 * 768 * 568 / (line["ms_per_step"] * 1e-3) / 1e6) / line["value"] < 1e-3
 
 
+def test_bench_two_ranks_issue_the_same_collectives_over_many_steps():
+    """Two ranks, the default settling phase (its length is agreed between the ranks: steps issue
+    collectives, so both must run the same number), and more timed steps than the pools of per-step rows
+    hold, so rows come round again and several collectives of 8 steps' rows each are issued on the way."""
+    line = _bench_line("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "150", "--warmup", "3", "--batch", "12",
+                       "--no-cpu-baseline")
+    assert line["n_gpus"] == 2 and line["steps"] == 150
+    total = line["dataset"]["histogram_pixels"]  # the last step's row, summed over both ranks, and nothing else
+    assert 12 * 768 * 568 < total <= 2 * 12 * 768 * 568
+
+
 def test_bench_two_ranks_reduce_class_statistics_in_one_collective():
     line = _bench_line("--gpus", "2", "--rehearse-on-one-gpu", "--workload", "P-C", "--steps", "2", "--warmup", "1",
                        "--batch", "9", "--settle-ms", "0", "--no-cpu-baseline")
