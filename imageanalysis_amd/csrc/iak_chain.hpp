@@ -16,11 +16,17 @@ struct ChainStage {
     const uint8_t *plane;  // C_GAUSS: rv plane, C_SP: keep-mask plane, C_KMEANS: int32 initial centroids [B][2]
     const uint8_t *plane2; // C_SP: salt-mask plane
     int lut_slot;          // C_CONST_LUT: index into ChainDesc::const_lut
+    // C_SP, where the noise is sparse enough: the noisy pixel indices as a sorted list (2 * index + salt) and,
+    // per 16-pixel chunk of the image, the first entry at or behind it ([N / 16 + 1])
+    const uint32_t *sp_ptr, *sp_list;
 };
 struct ChainDesc {
-    int n;
+    int n = 0;
     ChainStage st[CHAIN_MAX];
     uint8_t const_lut[2][256];  // at most two constant tables per chain
+    // > 0: the first compose_n stages are look-up stages and the table prologue leaves their composition
+    // (stage compose_n - 1 of stage ... of stage 0) in the slot of stage compose_n - 1
+    int compose_n = 0;
 };
 
 // LDS image of one image's tables

@@ -52,7 +52,7 @@ __device__ __forceinline__ void hist_accumulate_block(const uint32_t *__restrict
 __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *hist_in, int numPixels, ChainDesc d,
                                                          uint16_t *__restrict__ tables, uint32_t *hist_out = nullptr,
                                                          int n_images = 0x7fffffff, const uint32_t *acc_hist = nullptr,
-                                                         unsigned long long *acc_sum = nullptr) {
+                                                         unsigned long long *acc_sum = nullptr, uint8_t *lgs_tab = nullptr) {
     if ((int)blockIdx.x >= n_images) {  // uniform over the workgroup
         hist_accumulate_block(acc_hist, n_images, acc_sum, (int)blockIdx.x - n_images);
         return;
@@ -63,11 +63,16 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *hist_in
     float *pdf = bs.fbuf;
     long long *red = bs.red;
     __shared__ float ms[2];
+    __shared__ uint16_t stage_lut[256];
     const int b = blockIdx.x;
     const int v = threadIdx.x;
+    uint32_t composed = (uint32_t)v;  // value v after the look-up stages so far (d.compose_n > 0)
     h[v] = hist_in ? hist_in[(long long)b * 256 + v] : 0u;
     __syncthreads();
     uint16_t *tb = tables + (long long)b * CHAIN_MAX * 256;
+    // lgs_tab: the byte tables of lgs_stencil8_flat_kernel as well (composed look-up, amplitudes, NaN flags)
+    uint8_t *lt = lgs_tab ? lgs_tab + (long long)b * LGS_TAB_BYTES : nullptr;
+    if (lt && v == 0) *reinterpret_cast<uint32_t *>(lt + LGS_TAB_ANY) = 0u;
     for (int s = 0; s < d.n; s++) {
         const ChainStage st = d.st[s];
         if (st.type == C_SP) continue;
@@ -84,7 +89,14 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *hist_in
                 ms[1] = st.stddev * st.stddev;
             }
             __syncthreads();
-            tb[s * 256 + v] = gauss_entry(v, ms[0], ms[1]);
+            const uint16_t entry = gauss_entry(v, ms[0], ms[1]);
+            tb[s * 256 + v] = entry;
+            if (lt) {
+                lt[LGS_TAB_AMP + v] = (uint8_t)entry;
+                lt[LGS_TAB_NAN + v] = (entry & 0x100u) ? 0xff : 0;
+                const int any = __syncthreads_or(entry & 0x100u);
+                if (v == 0) *reinterpret_cast<uint32_t *>(lt + LGS_TAB_ANY) = any ? 1u : 0u;
+            }
             __syncthreads();
             continue;  // position-dependent from here on: the planner never asks for h again
         }
@@ -137,7 +149,16 @@ __global__ __launch_bounds__(256) void chain_prep_kernel(const uint32_t *hist_in
         } else {
             lut = d.const_lut[st.lut_slot][v];
         }
-        tb[s * 256 + v] = (uint16_t)lut;
+        if (s < d.compose_n) {
+            // the run's look-up stages as one table: stage s applied to what the stages before made of v
+            stage_lut[v] = (uint16_t)lut;
+            __syncthreads();
+            composed = stage_lut[composed];
+            tb[s * 256 + v] = (uint16_t)(s == d.compose_n - 1 ? composed : lut);
+            if (lt && s == d.compose_n - 1) lt[LGS_TAB_LUT + v] = (uint8_t)composed;
+        } else {
+            tb[s * 256 + v] = (uint16_t)lut;
+        }
         h2[v] = 0;
         // zeros are not in h: bin 0 holds numPixels - sum(others)
         const long long nonzero = block_sum_ll((long long)hv, red);
@@ -258,6 +279,8 @@ struct Group {
     bool hist_tracked = false;      // G_CHAIN: the prologue has the input's histogram and every stage carries it on
     bool binary = false;     // G_CHAIN_OP: the run is one threshold, the stencil is done by table (bt)
     BinTable bt;
+    bool lgs = false;        // G_CHAIN_OP: the run has the look-ups / Gaussian / salt-and-pepper shape (lgsd)
+    LgsDesc lgsd;
 };
 
 // operators the fused chain+stencil kernel can take over (the 8-pixel 3x3 family)
@@ -325,6 +348,7 @@ struct iak_pipeline {
     int32_t *map = nullptr;     // [maxB][256]
     int32_t *thr = nullptr;     // [maxB]
     uint16_t *tables = nullptr; // [maxB][CHAIN_MAX][256]
+    uint8_t *lgs_tab = nullptr; // [maxB][LGS_TAB_BYTES]
     uint32_t *x0 = nullptr, *x1 = nullptr;
     uint8_t *rv = nullptr;
     // k-means: the libc rand() state the centroid draws continue from run to run, and the draws
@@ -342,6 +366,13 @@ struct iak_pipeline {
     // by the keep-mask and salt-mask planes the fused chain passes read
     std::vector<std::pair<int, uint8_t *>> sp;
     long long plane_pitch = 0;
+    // level -> the same noise as a sorted list of the noisy pixel indices (2 * index + salt) behind a
+    // per-16-pixel-chunk offset array; only for levels whose noise is sparse (see lgs_stencil8_flat_kernel)
+    struct SpSparse {
+        int level;
+        uint32_t *ptr, *list;
+    };
+    std::vector<SpSparse> sp_sparse;
     // concurrency: the batch is cut into `lanes` sub-batches that run on their own streams, so
     // that bandwidth-bound and issue-bound kernels of different sub-batches overlap
     int lanes = 1;
@@ -364,13 +395,22 @@ struct iak_pipeline {
             if (e.first == level) return e.second;
         return nullptr;
     }
+    const SpSparse *sp_sparse_of(int level) const {
+        for (auto &e : sp_sparse)
+            if (e.level == level) return &e;
+        return nullptr;
+    }
 };
 
 static void free_all(iak_pipeline *p) {
-    void *ptrs[] = {p->bufA, p->bufB, p->hist_ring, p->map, p->thr, p->tables, p->x0, p->x1, p->rv,
+    void *ptrs[] = {p->bufA, p->bufB, p->hist_ring, p->map, p->thr, p->tables, p->lgs_tab, p->x0, p->x1, p->rv,
                     p->rand_state, p->kmeans_init, p->feat_ws};
     for (void *q : ptrs) (void)hipFree(q);
     for (auto &e : p->sp) (void)hipFree(e.second);
+    for (auto &e : p->sp_sparse) {
+        (void)hipFree(e.ptr);
+        (void)hipFree(e.list);
+    }
     for (auto e : p->ev) (void)hipEventDestroy(e);
     for (auto e : p->fork_join) (void)hipEventDestroy(e);
     for (auto st : p->aux) (void)hipStreamDestroy(st);
@@ -432,6 +472,35 @@ static int eval_binary_table(const iak_op &o, BinTable *bt) {
     return rc;
 }
 
+// The salt-and-pepper code plane of a level as the list form the shaped chain pass reads (host work, pipeline
+// creation only).  Levels whose noise touches more than one pixel in eight, and images the flat pass does not
+// take, keep the mask planes only.
+static int make_sp_sparse(iak_pipeline *p, int level, const uint8_t *code_plane) {
+    const long long N = p->N;
+    if (p->W % 16 != 0 || !tile_geometry(p->W, p->H).flat || N >= (1LL << 30)) return 0;
+    std::vector<uint8_t> code((size_t)N);
+    IAK_HIP(hipMemcpy(code.data(), code_plane, (size_t)N, hipMemcpyDeviceToHost));
+    const long long nc = N / 16;
+    std::vector<uint32_t> ptr((size_t)nc + 1), list;
+    for (long long c = 0; c < nc; c++) {
+        ptr[(size_t)c] = (uint32_t)list.size();
+        for (int k = 0; k < 16; k++) {
+            const long long i = 16 * c + k;
+            if (code[(size_t)i]) list.push_back((uint32_t)(2 * i) | (code[(size_t)i] == 2 ? 1u : 0u));
+        }
+    }
+    ptr[(size_t)nc] = (uint32_t)list.size();
+    if ((long long)list.size() * 8 > N) return 0;
+    iak_pipeline::SpSparse e{level, nullptr, nullptr};
+    IAK_HIP(hipMalloc((void **)&e.ptr, sizeof(uint32_t) * ptr.size()));
+    p->sp_sparse.push_back(e);  // owned from here on (free_all)
+    IAK_HIP(hipMalloc((void **)&p->sp_sparse.back().list, sizeof(uint32_t) * (list.size() + 1)));
+    IAK_HIP(hipMemcpy(p->sp_sparse.back().ptr, ptr.data(), sizeof(uint32_t) * ptr.size(), hipMemcpyHostToDevice));
+    if (!list.empty())
+        IAK_HIP(hipMemcpy(p->sp_sparse.back().list, list.data(), sizeof(uint32_t) * list.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
 static int plan(iak_pipeline *p) {
     p->groups.clear();
     Group g0;
@@ -449,6 +518,7 @@ static int plan(iak_pipeline *p) {
             g.kind = G_CHAIN;
             g.alg_bytes = 0;
             g.chain.n = 0;
+            g.chain.compose_n = 0;
             int luts = 0;
             bool chain_hist = hist_known;  // histogram tracked through the chain
             bool first = true;
@@ -498,6 +568,10 @@ static int plan(iak_pipeline *p) {
                     st.type = C_SP;
                     st.plane = p->sp_plane(q.iparam) + p->plane_pitch;
                     st.plane2 = st.plane + p->plane_pitch;
+                    if (const auto *sparse = p->sp_sparse_of(q.iparam)) {
+                        st.sp_ptr = sparse->ptr;
+                        st.sp_list = sparse->list;
+                    }
                     break;
                 }
                 g.chain.st[g.chain.n++] = st;
@@ -554,6 +628,12 @@ static int plan(iak_pipeline *p) {
                 g.alg_bytes += op_alg_bytes(p->ops[i].op.type);
                 g.name += std::string("+") + op_name(p->ops[i].op.type);
                 i++;
+                // look-ups, then Gaussian noise, then sparse salt-and-pepper, on an image one tile wide: the
+                // pass that knows this shape; the table prologue composes the look-up stages for it
+                if (!g.binary && tile_geometry(p->W, p->H).flat && !getenv("IAK_NO_LGS") && lgs_from_chain(g.chain, &g.lgsd)) {
+                    g.lgs = true;
+                    g.chain.compose_n = g.lgsd.lut_slot + 1;
+                }
             }
             p->groups.push_back(g);
             hist_known = false;  // conservative: a later consumer re-measures
@@ -710,6 +790,7 @@ int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op
     TRY(hipMalloc((void **)&p->map, sizeof(int32_t) * 256 * (size_t)maxB));
     TRY(hipMalloc((void **)&p->thr, sizeof(int32_t) * (size_t)maxB));
     TRY(hipMalloc((void **)&p->tables, sizeof(uint16_t) * 256 * CHAIN_MAX * (size_t)maxB));
+    TRY(hipMalloc((void **)&p->lgs_tab, (size_t)LGS_TAB_BYTES * (size_t)maxB));
     if (p->n_kmeans) {
         TRY(hipMalloc((void **)&p->rand_state, sizeof(uint32_t) * IAK_GLIBC_RAND_WORDS));
         TRY(hipMalloc((void **)&p->kmeans_init, sizeof(int32_t) * 2 * (size_t)p->n_kmeans * (size_t)maxB));
@@ -739,6 +820,7 @@ int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op
                                        pl + p->plane_pitch, pl + 2 * p->plane_pitch, p->N);
                     rc = (int)hipGetLastError();
                 }
+                if (rc == 0) rc = make_sp_sparse(p, c.op.iparam, pl);
             }
         if (rc == 0) rc = (int)hipStreamSynchronize(nullptr);
         if (rc != 0) { free_all(p); delete p; return rc; }
@@ -814,6 +896,7 @@ struct Slice {
     uint32_t *hist, *hist2;
     int32_t *map, *thr;
     uint16_t *tables;
+    uint8_t *lgs_tab;
 };
 
 static Slice slice_of(const iak_pipeline *p, int b0) {
@@ -825,6 +908,7 @@ static Slice slice_of(const iak_pipeline *p, int b0) {
     s.map = p->map + (size_t)b0 * 256;
     s.thr = p->thr + b0;
     s.tables = p->tables + (size_t)b0 * CHAIN_MAX * 256;
+    s.lgs_tab = p->lgs_tab + (size_t)b0 * LGS_TAB_BYTES;
     return s;
 }
 
@@ -916,10 +1000,10 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
         hist2_clear = false;
         return was;
     };
-    auto launch_prep = [&](const ChainDesc &cd, uint32_t *hist_out) {
+    auto launch_prep = [&](const ChainDesc &cd, uint32_t *hist_out, bool lgs = false) {
         const int extra = pending_sum ? (B + ACC_IMAGES - 1) / ACC_IMAGES : 0;
         hipLaunchKernelGGL(chain_prep_kernel, dim3(B + extra), dim3(256), 0, s, cur_hist, (int)N, cd, sl.tables, hist_out, B,
-                           (const uint32_t *)ghist, pending_sum);
+                           (const uint32_t *)ghist, pending_sum, lgs ? sl.lgs_tab : (uint8_t *)nullptr);
         pending_sum = nullptr;
     };
     for (int gi = 0; gi < ng; gi++) {
@@ -1000,7 +1084,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             for (int k = 0; k < g.chain.n; k++)
                 if (g.chain.st[k].plane && g.chain.st[k].type != C_KMEANS && !aligned16(g.chain.st[k].plane))
                     return IAK_E_UNSUPPORTED;
-            launch_prep(cd, nullptr);
+            launch_prep(cd, nullptr, g.lgs);
             IAK_LAUNCH_CHECK();
             if (ev) {
                 p->split[gi] = 1;
@@ -1013,6 +1097,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
                 break;
             }
             auto go = [&](const auto &op) {
+                if (g.lgs) return launch_lgs_stencil(cur, dst, p->W, p->H, B, N, N, g.lgsd, sl.lgs_tab, op, s);
                 return launch_chain_stencil(cur, dst, p->W, p->H, B, N, N, cd, sl.tables, op, s);
             };
             switch (o.type) {
