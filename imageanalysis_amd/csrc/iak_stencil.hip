@@ -232,7 +232,7 @@ __device__ __forceinline__ Raw16 load_raw_any(__amdgpu_buffer_rsrc_t rsrc, const
 template <class Op, int RPL, bool HIST = false, bool ANYW = false>
 __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W,
                                                        int H, long long in_stride, long long out_stride, Op op,
-                                                       uint32_t *__restrict__ hist = nullptr) {
+                                                       uint32_t *__restrict__ hist = nullptr, uint32_t chunks_magic = 0) {
     __shared__ uint32_t sh[HIST ? 256 * HIST_COLS : 1];
     if (HIST) hist_zero(sh);
     const int hcol = threadIdx.x & (HIST_COLS - 1);
@@ -240,11 +240,15 @@ __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict
     uint8_t *dst = out + (long long)blockIdx.y * out_stride;
     const int N = W * H;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
+    // the aligned form stores through a descriptor of the output image as well: 32-bit offsets, and rows below
+    // the image's last one (the last strip may have some) are dropped by the range check
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, N, 0x00020000);
     const int chunks = ANYW ? (W + 7) >> 3 : W >> 3;
     const int strips = (H + RPL - 1) / RPL;
     const int items = chunks * strips;
     for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < items; it += gridDim.x * blockDim.x) {
-        const int strip = it / chunks;
+        // chunks_magic = ceil(2^32 / chunks) where the launcher has checked that the product gives it / chunks
+        const int strip = chunks_magic ? (int)__umulhi((uint32_t)it, chunks_magic) : it / chunks;
         const int cx = it - strip * chunks;
         const int col0 = cx << 3;
         const int y0 = strip * RPL;
@@ -254,8 +258,12 @@ __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict
 #pragma unroll
             for (int r = 0; r < RPL + 2; r++) raw[r] = load_raw_any(rsrc, src, N, voff + r * W);
         } else {
+            int vo = voff;
 #pragma unroll
-            for (int r = 0; r < RPL + 2; r++) raw[r] = load_raw(rsrc, voff + r * W);
+            for (int r = 0; r < RPL + 2; r++) {
+                raw[r] = load_raw(rsrc, vo);
+                vo += W;
+            }
             if (y0 == 0 && col0 == 0) {
                 // the very first chunk of the image: offset -4 is out of range as a whole on some
                 // range-check implementations, so fetch from 0 and shift the dwords up by one
@@ -264,6 +272,8 @@ __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict
             }
         }
         const int valid = ANYW ? W - col0 : 8;  // outputs of this chunk that exist
+        const uint32_t first_col = col0 == 0 ? 0xffffff00u : 0xffffffffu;  // col < 1; col > W-1 cannot happen
+        int ooff = voff + W + 4;  // y0 * W + col0
         typename Op::Row up, mid, dn;
         op.prepare(raw[0], y0 - 1, col0, W, H, up);
         op.prepare(raw[1], y0, col0, W, H, mid);
@@ -274,14 +284,20 @@ __global__ __launch_bounds__(256) void stencil8_kernel(const uint8_t *__restrict
             uint32_t o[2];
             op.compute(up, mid, dn, o);
             if (Op::kBorderZero) {
-                if (row < 1) o[0] = o[1] = 0;        // row > H-1 cannot happen
-                if (col0 == 0) o[0] &= 0xffffff00u;  // col < 1; col > W-1 cannot happen
+                if (r == 0 && row < 1) o[0] = o[1] = 0;  // row > H-1 cannot happen
+                o[0] &= first_col;
             }
-            if (row < H) {
+            if (!ANYW) {
+                const u32x2 ov = {o[0], o[1]};
+                __builtin_amdgcn_raw_buffer_store_b64(ov, rs_out, ooff, 0, IAK_NT_STENCIL_ST ? 2 : 0);
+                ooff += W;
+                if (HIST && row < H) {
+                    hist_add4(sh, o[0], hcol);
+                    hist_add4(sh, o[1], hcol);
+                }
+            } else if (row < H) {
                 uint8_t *q = dst + (long long)row * W + col0;
-                if (!ANYW) {
-                    st8<IAK_NT_STENCIL_ST>(q, o[0], o[1]);
-                } else if (valid >= 8) {
+                if (valid >= 8) {
                     st8_unaligned(q, o[0], o[1]);
                 } else {
                     const uint64_t keep = (1ull << (8 * valid)) - 1;  // valid in [1, 7]
@@ -319,9 +335,14 @@ static int launch8(const uint8_t *in, uint8_t *out, int W, int H, int B, long lo
     const long long items = (long long)((W + 7) >> 3) * ((H + 7) / 8);
     if (hist && !hist_cleared) IAK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * 256 * (size_t)B, s));
     const dim3 grid(blocks_x(items, 256, B, hist ? 4096 : 1 << 20), B);
+    // item / chunks as a multiplication: exact while item * (magic * chunks - 2^32) < 2^32
+    const uint32_t chunks = (uint32_t)((W + 7) >> 3);
+    uint32_t chunks_magic = (uint32_t)(((1ULL << 32) + chunks - 1) / chunks);
+    if ((unsigned long long)items * ((unsigned long long)chunks_magic * chunks - (1ULL << 32)) >= (1ULL << 32) || chunks == 1)
+        chunks_magic = 0;
 #define IAK_LAUNCH8(HIST, ANYW)                                                                                       \
     hipLaunchKernelGGL((stencil8_kernel<Op, 8, HIST, ANYW>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, \
-                       op, hist)
+                       op, hist, chunks_magic)
     if (hist) {
         if (anyw) IAK_LAUNCH8(true, true); else IAK_LAUNCH8(true, false);
     } else {

@@ -314,13 +314,12 @@ struct Sobel8 {
     __device__ __forceinline__ void compute(const SobelRow &u, const SobelRow &m, const SobelRow &d, uint32_t o[2]) const {
         const h16x2 two = {(_Float16)2, (_Float16)2};
         const h16x2 top = __builtin_bit_cast(h16x2, 0x00ff00ffu);  // 255 * 2^-24 twice
-        // 0.5 in units of 2^-48.  The empty asm hides the constant from the compiler, which otherwise
-        // re-creates it with a move in front of every dot product (the two-address form overwrites
-        // its addend); as a live register it is used in the three-address form.  The dot products stay
-        // compiler-generated: the wait states this chip needs between a dot product and the instruction
-        // that reads its result are the compiler's to insert, and it cannot see into asm text.
-        float half_q = 0x1p-49f;
-        asm("" : "+v"(half_q));
+        // 0.5 in units of 2^-48, added by the dot products.  They are written as asm text in their three-address
+        // form: the compiler selects the two-address form, which overwrites its addend, and re-creates the constant
+        // with a move in front of every one of them (an instruction per pixel).  This chip needs three wait states
+        // between a dot product and a different kind of instruction that reads its result, and the compiler cannot
+        // see into asm text: the two dot products of a pixel pair share one block that ends with those wait states.
+        const float half_q = 0x1p-49f;
         const float magic = 8388607.5f;                            // 2^23 - 0.5: one binade below the sums
         uint32_t res[8];
 #pragma unroll
@@ -331,8 +330,14 @@ struct Sobel8 {
             // (gx, gy) of one pixel side by side, then gx*gx + gy*gy + 0.5 in one dot product
             const h16x2 g0 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(GY, GX, 0x05040100u));
             const h16x2 g1 = __builtin_bit_cast(h16x2, __builtin_amdgcn_perm(GY, GX, 0x07060302u));
-            const float y0 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fdot2(g0, g0, half_q, false));
-            const float y1 = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fdot2(g1, g1, half_q, false));
+            float q0, q1;
+            asm("v_dot2_f32_f16 %0, %2, %2, %4\n\t"
+                "v_dot2_f32_f16 %1, %3, %3, %4\n\t"
+                "s_nop 2"
+                : "=&v"(q0), "=&v"(q1)
+                : "v"(__builtin_bit_cast(uint32_t, g0)), "v"(__builtin_bit_cast(uint32_t, g1)), "v"(half_q));
+            const float y0 = __builtin_amdgcn_sqrtf(q0);
+            const float y1 = __builtin_amdgcn_sqrtf(q1);
             res[2 * k] = __builtin_bit_cast(uint32_t, __builtin_fmaf(y0, 0x1p24f, magic));
             res[2 * k + 1] = __builtin_bit_cast(uint32_t, __builtin_fmaf(y1, 0x1p24f, magic));
         }
