@@ -50,9 +50,20 @@ def parse_args(argv=None):
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks that all use GPU 0 and reduce over gloo: exercises the launch, sharding and reduction "
                          "code on a one-GPU machine.  The line it prints is marked as a rehearsal, not a measurement")
+    ap.add_argument("--rehearse-async", action="store_true",
+                    help="with --rehearse-on-one-gpu: issue the gloo all-reduces asynchronously with the bookkeeping of the "
+                         "RCCL path (two in flight, waited for when their rows come round again, the partial bucket flushed "
+                         "by the drain), on host copies of the rows, instead of reducing each bucket synchronously")
     ap.add_argument("--hang-dump-s", type=float, default=0.0,
                     help="debugging aid: write every thread's Python stack to stderr if the run is still going after "
                          "this many seconds")
+    ap.add_argument("--max-seconds", type=float, default=900.0,
+                    help="a run that is still going after this long writes every thread's stack and the state of its "
+                         "collectives to stderr and exits with status 3 (no rank of a multi-GPU job can hang silently); "
+                         "0 disables")
+    ap.add_argument("--dataset-out", default="",
+                    help="rank 0 writes the data-set level sums the last step's reduction left (the histogram; with feature "
+                         "extraction also the per-class count, feature sums and sums of squares) to this JSON file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="default P-A run only: skip the short P-B / P-C / configuration-kernel measurements")
@@ -125,7 +136,7 @@ P_A = p_a_ops()
 KERNEL_OF_GROUP = {
     "gray+hist": "iak::gray_kernel<0, true>",
     "equalize+gauss+salt_pepper+linear+median+sobel": "iak::strip_kernel",
-    "equalize+gauss+salt_pepper+linear": "iak::chain_stencil8_flat_kernel<iak::Lin8Swar>",
+    "equalize+gauss+salt_pepper+linear": "iak::lgs_stencil8_flat_kernel<iak::Lin8Swar>",
     "equalize+gauss+salt_pepper": "iak::chain_apply_kernel<false>",
     "linear": "iak::stencil8_kernel<iak::Lin8Swar, 8, false, false>",
     "median": "iak::stencil8_kernel<iak::Median8, 8, false, false>",
@@ -133,7 +144,7 @@ KERNEL_OF_GROUP = {
 }
 # kernels behind the group names of the other workloads, where they differ from P-A's
 KERNEL_OF_GROUP_BY_WORKLOAD = {
-    "P-A/config": {"equalize+gauss+salt_pepper+linear": "iak::chain_stencil8_flat_kernel<iak::Lin8Pk16<false> >",
+    "P-A/config": {"equalize+gauss+salt_pepper+linear": "iak::lgs_stencil8_flat_kernel<iak::Lin8Pk16<false> >",
                    "linear": "iak::stencil8_kernel<iak::Lin8Pk16<false>, 8, false, false>"},
     "P-B": {"linear": "iak::box_special_kernel<false, 11>", "median": "iak::column_hist_median_kernel<7, 2>"},
     "P-C": {"otsu": "iak::chain_apply_kernel<false>", "otsu+sobel": "iak::binary_table_stencil_kernel",
@@ -156,6 +167,8 @@ WORKLOADS = {
     "P-C": (P_C, 768, 568, 500, 14, "segmentation path (gray, histogram, otsu, sobel, 3x3 dilation, 3x3 erosion, "
             "7 features per image, per-class feature statistics)"),
 }
+CONFIG3_IMAGES_PER_GPU = 1250  # BASELINE config 3: 10 000 images of 768x568 sharded image-wise over 8 GPUs
+LLC_BYTES = 256 << 20  # Infinity Cache: an intermediate batch no larger than this is still on the die for the next pass
 HIST_POOL = 64  # int64[256] rows the steps' data-set histograms take turns through (see Measurement)
 N_CLASSES = 6  # the data set's class count (imageMachineLearning.cu:212); synthetic label = image index % 6
 
@@ -227,6 +240,31 @@ def _load_profile_json(name):
         return {}
 
 
+class Watchdog:
+    """Ends the process (status 3) if the run outlives its budget: dumps every thread's Python stack and what
+    `state()` reports (which step, which collectives are in flight) first."""
+
+    def __init__(self, seconds, state):
+        import threading
+        self.deadline = time.monotonic() + seconds
+        self.state = state
+        self.done = threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        import faulthandler
+        while not self.done.wait(1.0):
+            if time.monotonic() > self.deadline:
+                sys.stderr.write(f"bench.py: still running at its time limit; state: {self.state()}\n")
+                faulthandler.dump_traceback(file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(3)
+
+    def stop(self):
+        self.done.set()
+
+
 def init_dist(args, world, local_rank, dev):
     """RCCL (or gloo for the one-GPU rehearsal) up, first collective done.  RCCL writes its
     version banner to stdout when the communicator comes up; stdout is reserved for the one JSON
@@ -236,8 +274,13 @@ def init_dist(args, world, local_rank, dev):
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
+        import datetime
         backend = "gloo" if args.rehearse_on_one_gpu else "nccl"
-        kw = {} if backend == "gloo" else {"device_id": dev}
+        # a collective that has not completed after this long aborts the job (gloo raises; for RCCL torch's
+        # watchdog thread ends the process) instead of waiting for a peer for ever
+        kw = {"timeout": datetime.timedelta(seconds=180)}
+        if backend == "nccl":
+            kw["device_id"] = dev
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
@@ -252,6 +295,17 @@ def init_dist(args, world, local_rank, dev):
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     return dist
+
+
+class _HostCollective:
+    """An asynchronous collective on a host copy of device rows; wait() brings the result back."""
+
+    def __init__(self, work, host, rows):
+        self.work, self.host, self.rows = work, host, rows
+
+    def wait(self):
+        self.work.wait()
+        self.rows.copy_(self.host)
 
 
 class Measurement:
@@ -287,6 +341,9 @@ class Measurement:
             self.packed = [PackedDatasetStats(N_CLASSES, dev, buf=self.packed_pool[r]) for r in range(HIST_POOL)]
         self.pending = []       # collectives in flight, oldest first
         self.via_host = bool(args.rehearse_on_one_gpu)
+        self.host_async = bool(args.rehearse_async)
+        self.issued = self.waited = 0  # collectives handed to the backend / waited for (for the watchdog's report)
+        self.phase = "set-up"
         self.bucket_start = 0   # first row of the steps not handed to a collective yet
         self.bucket_rows = 0
         self.counter = 0
@@ -299,9 +356,12 @@ class Measurement:
         pool = self.packed_pool if self.feats is not None else self.hist_pool
         rows = pool[self.bucket_start:self.bucket_start + self.bucket_rows]
         self.bucket_rows = 0
-        if self.via_host:
-            # The gloo rehearsal reduces a host copy, synchronously: gloo's collectives on device tensors,
-            # issued asynchronously between kernel launches, were seen to stall for good on a shared GPU.
+        if self.via_host and not self.host_async:
+            # The gloo rehearsal reduces a host copy: gloo's collectives on DEVICE tensors, issued asynchronously
+            # between kernel launches, stall for good with two ranks on one GPU even when both ranks issue exactly
+            # the same collectives (both ranks end up in drain(), gloo's transport waiting for a receive that never
+            # comes: its worker threads and device-side copies, not this bookkeeping -- RCCL's wait() is a
+            # stream-side dependency with no worker thread).
             host = rows.cpu()
             self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM)
             rows.copy_(host)
@@ -309,8 +369,24 @@ class Measurement:
         # At most two collectives in flight (wait() orders this stream after the collective without
         # blocking the host).
         while len(self.pending) >= 2:
-            self.pending.pop(0).wait()
-        self.pending.append(self.dist.all_reduce(rows, op=self.dist.ReduceOp.SUM, async_op=True))
+            self._wait(self.pending.pop(0))
+        if self.via_host:
+            # the same issue / wait pattern over gloo, on a host copy that travels back when the collective is waited for
+            host = rows.cpu()
+            self.pending.append(_HostCollective(self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, async_op=True), host, rows))
+        else:
+            self.pending.append(self.dist.all_reduce(rows, op=self.dist.ReduceOp.SUM, async_op=True))
+        self.issued += 1
+
+    def _wait(self, work):
+        """Orders this stream behind the collective.  RCCL: no host wait.  gloo: blocks the host until its worker
+        thread has run the collective, and raises after the process group's time limit."""
+        work.wait()
+        self.waited += 1
+
+    def state(self):
+        return {"phase": self.phase, "step": self.counter, "collectives_issued": self.issued,
+                "collectives_waited_for": self.waited, "in_flight": len(self.pending), "bucket_rows": self.bucket_rows}
 
     def step(self):
         # the batch's grayscale histogram is added to this step's row by the run; across GPUs the
@@ -319,7 +395,7 @@ class Measurement:
         if self.counter >= HIST_POOL and row % (HIST_POOL // 2) == 0:
             # this half comes round again: its collectives were issued at least half a pool ago
             for w in self.pending[:-1]:
-                w.wait()
+                self._wait(w)
             del self.pending[:-1]
             self.hist_pool[row:row + HIST_POOL // 2].zero_()
         self.counter += 1
@@ -336,10 +412,11 @@ class Measurement:
     def drain(self):
         self._reduce_bucket()
         for w in self.pending:
-            w.wait()
+            self._wait(w)
         self.pending = []
 
     def run(self, steps, warmup, settle_ms, events=True):
+        self.phase = "settling"
         if settle_ms > 0 and self.dist is None:
             # The GPU has been idle or running small torch kernels while the inputs were made; its clocks take
             # some tens of milliseconds of load to come back up.  Untimed, like the warm-up steps.
@@ -362,6 +439,7 @@ class Measurement:
             for _ in range(min(int(more.item()), 2000)):
                 self.step()
             torch.cuda.synchronize()
+        self.phase = "warm-up"
         for _ in range(warmup):
             self.step()
         # per-kernel HIP events on a sample of the timed steps (every 8th, at least one): each timed
@@ -374,14 +452,17 @@ class Measurement:
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        self.phase = "timed steps"
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
+        self.phase = "drain"
         self.drain()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        self.phase = "report"
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -408,28 +489,41 @@ class Measurement:
         px = B * W * H
         value = px * world * steps / dt / 1e6
         kernel_of = dict(KERNEL_OF_GROUP, **KERNEL_OF_GROUP_BY_WORKLOAD.get(variant or self.name, {}))
+        # Counter figures are not measured in this run: they come from the committed summaries of earlier rocprofv3
+        # --pmc passes (tools/profile_round.sh) and are used only where the kernel's name and the batch are the
+        # same as in this run; otherwise the field is left out (null in `roofline`).
         traffic = _load_profile_json("traffic.json")
-        valu = _load_profile_json("valu.json").get(variant or self.name, {})
+        valu_all = _load_profile_json("valu.json")
+        valu = valu_all.get(variant or self.name, {})
+        valu_batch = WORKLOADS[self.name][3]  # the counter passes run the workload's default batch
         tpx = timed_images * W * H
+        # an intermediate batch no larger than the Infinity Cache is still on the die when the next pass reads it
+        # (the passes store it with the default policy for that reason): such a pass does not read from HBM
+        llc = tpx <= LLC_BYTES
         groups = []
-        for (n, ms, stage_b, mm), mv in zip(self.groups, moved):
+        used_traffic = used_valu = False
+        for gi, ((n, ms, stage_b, mm), mv) in enumerate(zip(self.groups, moved)):
             g = {"name": n, "kernel": kernel_of.get(n, n), "ms": round(ms, 4), "kernel_ms": round(mm, 4), "images": timed_images,
-                 "moved_bytes_per_px": mv, "stagewise_bytes_per_px": stage_b}
+                 "moved_bytes_per_px": mv, "stagewise_bytes_per_px": stage_b,
+                 "input_from": "hbm" if (gi == 0 or not llc) else "infinity-cache"}
             if mm > 0:
                 gbps = mv * tpx / (mm * 1e-3) / 1e9
                 g["moved_GBps"] = round(gbps, 1)
+                # moved bytes / duration over the HBM peak; a true HBM fraction only where input_from is "hbm"
                 g["hbm_frac"] = round(gbps / HBM_PEAK_GBS, 4)
                 g["bound"] = "hbm"
                 v = valu.get(kernel_of.get(n, n))
-                if v and B == WORKLOADS[self.name][3]:  # the counter passes run the default batch
+                if v and B == valu_batch:  # the counter passes run the default batch
                     # share of the launch during which the vector pipes were issuing, from the SQ counter pass
                     issue_s = v["valu_busy_simd_cycles_per_launch"] / N_SIMDS / CLOCK_HZ
                     g["valu_issue_frac"] = round(issue_s / (mm * 1e-3), 4)
+                    used_valu = True
                     if g["valu_issue_frac"] > g["hbm_frac"]:
                         g["bound"] = "valu"
                 tr = traffic.get(n)
                 if tr and tr.get("batch") == B and tr.get("kernel") == g["kernel"]:
                     g["traffic_bytes_per_launch"] = tr["hbm_bytes_per_launch"]
+                    used_traffic = True
             groups.append(g)
         moved_total = sum(moved)
         line = {
@@ -438,6 +532,9 @@ class Measurement:
             # fraction of HBM peak on the bytes the executed plan has to move (<= 1 by construction)
             "pipeline_hbm_frac_moved_bytes": round(value * 1e6 / world * moved_total / (HBM_PEAK_GBS * 1e9), 4),
             "pipeline_stagewise_bytes_per_px": self.stagewise_bytes,
+            "intermediates_llc_resident": bool(llc),
+            "traffic_source": f"profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, batch {B})" if used_traffic else None,
+            "valu_source": f"profiles/valu.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU pass, batch {valu_batch})" if used_valu else None,
             "groups": groups,
         }
         if groups and all("traffic_bytes_per_launch" in g for g in groups):
@@ -451,7 +548,8 @@ class Measurement:
             line["roofline"] = {"bound": dom.get("bound", "hbm"), "kernel": dom["kernel"], "group": dom["name"],
                                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": dom.get("traffic_bytes_per_launch"),
-                                "algorithmic_bytes_per_px": alg, "avg_ms": dom["kernel_ms"], "bytes_per_launch": alg * tpx}
+                                "algorithmic_bytes_per_px": alg, "avg_ms": dom["kernel_ms"], "bytes_per_launch": alg * tpx,
+                                "traffic_source": line["traffic_source"] if dom.get("traffic_bytes_per_launch") else None}
             if "valu_issue_frac" in dom:
                 line["roofline"]["valu_issue_frac"] = dom["valu_issue_frac"]
         return line
@@ -518,10 +616,16 @@ def main():
     iak_lib.load()
 
     ops = p_a_ops(args.linear_kernel) if args.workload == "P-A" else WORKLOADS[args.workload][0]
-    B = args.batch or WORKLOADS[args.workload][3]
+    # One GPU: BASELINE config 2's batch (500 images).  Several GPUs: config 3's per-GPU share -- 10 000 images
+    # over 8 GPUs = 1250 each, the same share at every GPU count (weak scaling).
+    config3 = world > 1 and not args.batch and args.workload != "P-B" and not args.rehearse_on_one_gpu
+    B = args.batch or (CONFIG3_IMAGES_PER_GPU if config3 else WORKLOADS[args.workload][3])
     variant = "P-A/config" if (args.workload == "P-A" and args.linear_kernel == "config") else None
     m = Measurement(args, args.workload, ops, B, dev, rank, dist, _mode_of(args))
+    dog = Watchdog(args.max_seconds, m.state) if args.max_seconds > 0 else None
     dt = m.run(args.steps, args.warmup, args.settle_ms, events=not args.no_events)
+    if dog:
+        dog.stop()
 
     if rank == 0:
         rep = m.report(dt, args.steps, world, variant=variant)
@@ -534,7 +638,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": rep["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"batch of {B} {W}x{H} RGB cell-like images per GPU, {what}, device-resident",
+            "config": {"workload": (f"BASELINE config 3 ({CONFIG3_IMAGES_PER_GPU * 8} images sharded image-wise over 8 GPUs): its per-GPU "
+                                    f"share, " if B == CONFIG3_IMAGES_PER_GPU and world > 1 else "") +
+                                   f"batch of {B} {W}x{H} RGB cell-like images per GPU, {what}, device-resident",
                        "images_per_gpu": B, "settle_ms": args.settle_ms,
                        "mode": "stagewise" if args.stagewise else ("fused-pointwise" if args.pointwise else ("fused-strips" if args.strips else "fused")),
                        "lanes": args.lanes,
@@ -551,10 +657,23 @@ def main():
                                "class_mean_area": [round(float(a), 3) for a in mean[:, 2].tolist()]}
         else:
             line["dataset"] = {"histogram_pixels": int(m.hist_rows[(m.counter - 1) % HIST_POOL].sum().item())}
+        if args.dataset_out:
+            sums = {}
+            if m.feats is not None:
+                pk = m.packed[k_last]
+                sums = {"histogram": [int(v) for v in pk.histogram().tolist()], "class_count": [int(v) for v in pk.count.round().tolist()],
+                        "class_sum": pk.sum.tolist(), "class_sumsq": pk.sumsq.tolist()}
+            else:
+                sums = {"histogram": [int(v) for v in m.hist_rows[k_last].tolist()]}
+            with open(args.dataset_out, "w") as f:
+                json.dump(sums, f)
         if args.rehearse_on_one_gpu:
-            line["rehearsal"] = "all ranks on GPU 0, gloo reduction: exercises the multi-rank code path; not a measurement"
+            line["rehearsal"] = ("all ranks on GPU 0, gloo reduction of host copies" +
+                                 (", issued asynchronously as the RCCL path issues its collectives" if args.rehearse_async else "") +
+                                 ": exercises the multi-rank code path; not a measurement")
         for k in ("pipeline_moved_bytes_per_px", "pipeline_hbm_frac_moved_bytes", "pipeline_hbm_frac_counter_traffic",
-                  "pipeline_stagewise_bytes_per_px", "groups", "roofline"):
+                  "pipeline_stagewise_bytes_per_px", "intermediates_llc_resident", "traffic_source", "valu_source", "groups",
+                  "roofline"):
             if k in rep:
                 line[k] = rep[k]
         solo = world == 1 and not args.force_dist

@@ -437,8 +437,9 @@ __global__ __launch_bounds__(CM_LANES) void column_hist_median_kernel(const uint
                                                                       int kH, int strips_x) {
     constexpr bool NIB = MODE != 0;
     constexpr int FINE_WORDS = NIB ? 32 : 64;
-    __shared__ uint32_t fine_all[FINE_WORDS * CM_LANES];   // [fine word][lane]
-    __shared__ uint32_t block_all[4 * CM_LANES];   // [block word][lane]
+    // 16-byte aligned: pairs of columns are read as 8-byte LDS loads
+    __shared__ __attribute__((aligned(16))) uint32_t fine_all[FINE_WORDS * CM_LANES];   // [fine word][lane]
+    __shared__ __attribute__((aligned(16))) uint32_t block_all[4 * CM_LANES];   // [block word][lane]
     constexpr int s = (KW - 1) / 2;
     constexpr int OUT_W = CM_LANES - 2 * s;  // columns a workgroup produces
     const int lane = threadIdx.x;

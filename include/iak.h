@@ -194,7 +194,9 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
  * the other shapes need image-sized scratch).  Every call on a GPU uses that GPU's one array, so
  * calls that overlap on one GPU (different streams, different host threads) race; calls on one
  * stream, or on streams ordered after one another, are fine.  Run it with the device current
- * whose memory img / features live in. */
+ * whose memory img / features live in.  The first call on a device looks up the array's address and
+ * builds host-side tables, which are not stream operations: make one ordinary (eager) call on each
+ * device before a call under graph capture. */
 int iak_features_static_max_images(void);
 int iak_features_static(const uint8_t *img, int W, int H, int B, long long stride, const uint32_t *hist,
                         float *features, void *stream);
@@ -304,7 +306,10 @@ int iak_pipeline_set_input(iak_pipeline *p, int input);
  * Runs of one pipeline are expected on one stream, or on streams ordered after one another (as
  * any use of its buffers requires): the executor's histogram tables are cleared eight runs'
  * worth at a time on the stream of the run that finds none clean, and a run on a different
- * stream than the previous one clears them again there. */
+ * stream than the previous one clears them again there.  Which tables a run uses, and whether it
+ * clears them, therefore depends on the runs before it: do NOT record a run into a HIP graph and
+ * replay it (the replays would add onto tables that nothing clears).  Under capture pass a gray_hist
+ * array of your own, which every run clears itself, or use the per-operation entry points. */
 int iak_pipeline_run(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int B,
                      unsigned long long *hist_sum, uint32_t *gray_hist, void *stream);
 /* Cuts every batch into `lanes` (1..8) consecutive sub-batches that run concurrently on

@@ -56,38 +56,76 @@ def _bench_line(*flags):
     return json.loads(lines[0])
 
 
-def test_bench_starts_its_own_ranks():
+def _rank_batches(n_ranks, B):
+    """The batches the ranks of a bench run hold: rank r's generator is seeded with 0x1A2B3C4D + r."""
+    import bench
+    bench.W, bench.H = 768, 568
+    return np.concatenate([bench.make_cell_batch(B, torch.device("cuda"), seed=0x1A2B3C4D + r).cpu().numpy() for r in range(n_ranks)])
+
+
+def _oracle_dataset_histogram(rgb):
+    x0, x1 = O.xorwow_planes(768 * 568)
+    _, h = O.pipeline(rgb, [], x0, x1, threads=min(16, os.cpu_count() or 1))
+    return h.astype(np.int64)
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher around it: the parent starts two ranks as a child
     process and relays rank 0's line.  Both ranks share this box's one GPU and reduce over gloo
-    (a rehearsal of the code path, not a measurement)."""
+    (a rehearsal of the code path, not a measurement).  The reduced data-set histogram is the oracle's
+    over both ranks' batches (test/test.cu:407-411 sums the same rows on one GPU)."""
+    sums = str(tmp_path / "sums.json")
     line = _bench_line("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "3", "--warmup", "1", "--batch", "12",
-                       "--settle-ms", "0", "--no-cpu-baseline")
+                       "--settle-ms", "0", "--no-cpu-baseline", "--dataset-out", sums)
     assert line["n_gpus"] == 2 and line["steps"] == 3 and "rehearsal" in line
     assert line["config"]["images_per_gpu"] == 12
-    # both ranks' histograms arrived: at most every pixel of 2 x 12 images, and more than one rank's worth
-    total = line["dataset"]["histogram_pixels"]
-    assert 12 * 768 * 568 < total <= 2 * 12 * 768 * 568
+    want = _oracle_dataset_histogram(_rank_batches(2, 12))
+    got = np.array(json.load(open(sums))["histogram"], dtype=np.int64)
+    assert np.array_equal(got, want)
+    assert line["dataset"]["histogram_pixels"] == int(want.sum())
     assert abs(line["value"] - 2 * 12 * 768 * 568 / (line["ms_per_step"] * 1e-3) / 1e6) / line["value"] < 1e-3
 
 
-def test_bench_two_ranks_issue_the_same_collectives_over_many_steps():
+def test_bench_two_ranks_issue_the_same_collectives_over_many_steps(tmp_path):
     """Two ranks, the default settling phase (its length is agreed between the ranks: steps issue
     collectives, so both must run the same number), and more timed steps than the pools of per-step rows
-    hold, so rows come round again and several collectives of 8 steps' rows each are issued on the way."""
-    line = _bench_line("--gpus", "2", "--rehearse-on-one-gpu", "--steps", "150", "--warmup", "3", "--batch", "12",
-                       "--no-cpu-baseline")
+    hold, so rows come round again and several collectives of 8 steps' rows each are issued on the way.
+    The collectives are issued with the RCCL path's bookkeeping: asynchronously, two in flight, waited for
+    when their rows come round again, the partial bucket flushed by the drain (--rehearse-async; over gloo
+    they travel as host copies of the rows)."""
+    sums = str(tmp_path / "sums.json")
+    line = _bench_line("--gpus", "2", "--rehearse-on-one-gpu", "--rehearse-async", "--steps", "150", "--warmup", "3",
+                       "--batch", "12", "--no-cpu-baseline", "--max-seconds", "200", "--dataset-out", sums)
     assert line["n_gpus"] == 2 and line["steps"] == 150
-    total = line["dataset"]["histogram_pixels"]  # the last step's row, summed over both ranks, and nothing else
-    assert 12 * 768 * 568 < total <= 2 * 12 * 768 * 568
+    # the last step's row, summed over both ranks, and nothing else
+    want = _oracle_dataset_histogram(_rank_batches(2, 12))
+    assert np.array_equal(np.array(json.load(open(sums))["histogram"], dtype=np.int64), want)
 
 
-def test_bench_two_ranks_reduce_class_statistics_in_one_collective():
+def test_bench_two_ranks_reduce_class_statistics_in_one_collective(tmp_path):
+    """P-C on two ranks: the packed row (histogram, per-class image count, feature sums and sums of squares,
+    test/test.cu:541-550) after the reduction against the oracle's features of both ranks' images."""
+    import bench
+    sums = str(tmp_path / "sums.json")
     line = _bench_line("--gpus", "2", "--rehearse-on-one-gpu", "--workload", "P-C", "--steps", "2", "--warmup", "1",
-                       "--batch", "9", "--settle-ms", "0", "--no-cpu-baseline")
+                       "--batch", "9", "--settle-ms", "0", "--no-cpu-baseline", "--dataset-out", sums)
     assert line["n_gpus"] == 2
     # labels are (global image index) % 6 over 2 x 9 images
     assert line["dataset"]["class_counts"] == [3, 3, 3, 3, 3, 3]
     assert "per-class feature statistics" in line["config"]["parallelism"]
+    got = json.load(open(sums))
+    rgb = _rank_batches(2, 9)
+    assert np.array_equal(np.array(got["histogram"], dtype=np.int64), _oracle_dataset_histogram(rgb))
+    x0, x1 = O.xorwow_planes(768 * 568)
+    image_ops = [o for o in bench.P_C if o["type"] != bench.OP_FEATURES]
+    img, _ = O.pipeline(rgb, image_ops, x0, x1, threads=min(16, os.cpu_count() or 1))
+    feats = np.stack([O.features(img[b]) for b in range(18)]).astype(np.float32).astype(np.float64)
+    labels = np.arange(18) % bench.N_CLASSES
+    assert got["class_count"] == [int((labels == c).sum()) for c in range(bench.N_CLASSES)]
+    for c in range(bench.N_CLASSES):
+        sel = feats[labels == c]
+        assert np.allclose(np.array(got["class_sum"][c]), sel.sum(axis=0), rtol=1e-12, atol=0)
+        assert np.allclose(np.array(got["class_sumsq"][c]), (sel * sel).sum(axis=0), rtol=1e-12, atol=0)
 
 
 def test_class_statistics_from_the_executor_features_match_the_oracle():

@@ -117,7 +117,7 @@ def test_driver_shards_the_folder_over_devices(folder, gpus):
     share the one device).  Images, the CSV with its labels and the k-means draws (a share that
     starts at file i continues the centroid stream from image i) are the one-device results."""
     d, rgb, want, feats = folder
-    out, stdout = run_driver(d, ["--batch", "--gpus", str(gpus), "--share-devices"], f"gpus{gpus}")
+    out, stdout = run_driver(d, ["--batch", "--gpus", str(gpus), "--share-devices", "--dataset-summary"], f"gpus{gpus}")
     check_outputs(out, want, feats)
     line = [l for l in stdout.splitlines() if l.startswith("Dataset histogram over")]
     assert len(line) == 1 and f"over {gpus} device(s)" in line[0]

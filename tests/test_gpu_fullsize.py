@@ -112,6 +112,78 @@ def test_config4_4096_square_large_windows(mods):
     assert np.array_equal(p.run(both).cpu().numpy(), got)
 
 
+def test_config4_batch_8_of_4096_square(mods):
+    """Config 4 at the bench's size: 8 images of 4096x4096 through gray -> 11x11 box (1/121) -> 7x7 median.
+    The first and the last image against the oracle; the whole batch again in reverse order, which must give
+    the same images in reverse order (no image's result depends on its place in the batch)."""
+    ops, Pipeline = mods
+    import bench
+    W = H = 4096
+    B = 8
+    old = bench.W, bench.H
+    bench.W, bench.H = W, H
+    try:
+        rgb = bench.make_cell_batch(B, torch.device("cuda"), seed=404)
+    finally:
+        bench.W, bench.H = old
+    p = Pipeline(W, H, B, bench.P_B)
+    got = p.run(rgb).clone()
+    pick = [0, B - 1]
+    want, _ = O.pipeline(rgb[pick].cpu().numpy(), bench.P_B, threads=2)
+    assert np.array_equal(got[pick].cpu().numpy(), want)
+    back = p.run(rgb.flip(0).contiguous())
+    assert torch.equal(back.flip(0), got)
+    # the filters' borders: 5 rows / columns of zeros from the box filter's rule, of which the median keeps 3 and
+    # may fill the rest with zeros or small values; the first three rows and columns are zero in every image
+    assert int(got[:, :3, :].max()) == 0 and int(got[:, :, :3].max()) == 0
+    p.close()
+
+
+def test_config5_batch_500_segmentation_path_with_features(mods):
+    """Config 5 at the bench's size: 500 images of 768x568 through gray -> Otsu -> Sobel -> 3x3 dilation ->
+    3x3 erosion (cross) -> 7 features per image, with the per-class statistics the multi-GPU job reduces.
+    Every image, every feature row, the data-set histogram and the packed class sums against the oracle
+    (imageMachineLearning.cu:393-422, test/test.cu:541-550)."""
+    import os
+    ops, Pipeline = mods
+    import bench
+    from imageanalysis_amd.dist import PackedDatasetStats
+    W, H, B, C = 768, 568, 500, bench.N_CLASSES
+    bench.W, bench.H = W, H
+    rgb = bench.make_cell_batch(B, torch.device("cuda"), seed=505)
+    p = Pipeline(W, H, B, bench.P_C)
+    feats = torch.zeros((B, 7), dtype=torch.float32, device="cuda")
+    p.bind_features(feats)
+    hist = torch.zeros(256, dtype=torch.int64, device="cuda")
+    out = p.run(rgb, hist_sum=hist)
+    labels = (torch.arange(B, device="cuda", dtype=torch.int64) % C).to(torch.int32)
+    packed = PackedDatasetStats(C, torch.device("cuda"))
+    packed.fill(hist, feats, labels)
+    torch.cuda.synchronize()
+    threads = min(16, os.cpu_count() or 1)
+    x0, x1 = O.xorwow_planes(W * H)
+    image_ops = [o for o in bench.P_C if o["type"] != bench.OP_FEATURES]
+    want_img, want_hist = O.pipeline(rgb.cpu().numpy(), image_ops, x0, x1, threads=threads)
+    got_img = out.cpu().numpy()
+    assert np.array_equal(got_img, want_img)
+    assert np.array_equal(packed.histogram().cpu().numpy(), want_hist)
+    pick = sorted(set([0, 249, 499] + list(range(7, B, 31))))
+    want = np.stack([O.features(want_img[b]) for b in pick]).astype(np.float64)
+    got = feats.cpu().numpy().astype(np.float64)
+    assert np.array_equal(got[pick], want)
+    # the class sums are sums of the feature rows the GPU wrote (all 500 of them, oracle-checked on `pick`)
+    lab = labels.cpu().numpy()
+    count, mean, std = (t.cpu().numpy() for t in packed.class_stats())
+    for c in range(C):
+        sel = got[lab == c]
+        assert count[c] == len(sel)
+        assert np.allclose(mean[c], sel.mean(axis=0), rtol=1e-12, atol=1e-9)
+        assert np.allclose(std[c], sel.std(axis=0), rtol=1e-6, atol=1e-4)
+    # a binary image comes out: erosion of a dilated mask
+    assert set(np.unique(got_img[::50]).tolist()) <= {0, 255}
+    p.close()
+
+
 def test_grayscale_pass_when_lanes_walk_more_than_two_chunks(mods):
     """A launch is capped at 16K workgroups; past that every lane of the grayscale pass walks further
     than the two chunks it is sized for.  3000 images of 768x284 (lanes take up to three chunks, the
