@@ -96,10 +96,12 @@ inline int box_classify(float w, int kW, int kH, BoxSpecial *sp) {
 // (A) of both kernels: a wave per row, lanes along it (two passes cover up to 88 columns); eight
 // rows' loads are issued before the first is used, so that their latencies overlap.
 // With `lut` (256 entries in LDS, ready before the call) the element is lut[pixel] instead.
+// Returns the OR of the elements this lane staged.
 template <bool SPECIAL>
-__device__ __forceinline__ void box_stage_tile(uint16_t *t1, __amdgpu_buffer_rsrc_t rsrc, int N, int W, int x0, int y0, int a,
-                                               int s, int IW, int IH, float w, const uint16_t *lut) {
+__device__ __forceinline__ uint32_t box_stage_tile(uint16_t *t1, __amdgpu_buffer_rsrc_t rsrc, int N, int W, int x0, int y0, int a,
+                                                   int s, int IW, int IH, float w, const uint16_t *lut) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t seen = 0;
     for (int rb = wave; rb < IH; rb += 32) {
         uint32_t v[8][2];
 #pragma unroll
@@ -122,11 +124,15 @@ __device__ __forceinline__ void box_stage_tile(uint16_t *t1, __amdgpu_buffer_rsr
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const int c = lane + 64 * k;
-                if (r < IH && c < IW)
-                    t1[r * BX_PITCH + c] = SPECIAL ? lut[v[u][k]] : (uint16_t)(uint32_t)((float)v[u][k] * w);
+                if (r < IH && c < IW) {
+                    const uint16_t e = SPECIAL ? lut[v[u][k]] : (uint16_t)(uint32_t)((float)v[u][k] * w);
+                    t1[r * BX_PITCH + c] = e;
+                    seen |= e;
+                }
             }
         }
     }
+    return seen;
 }
 
 // The same tile staged four pixels per load, for images whose rows start at multiples of 4 bytes
@@ -137,9 +143,10 @@ __device__ __forceinline__ void box_stage_tile(uint16_t *t1, __amdgpu_buffer_rsr
 // c + SH - s here.  IWs: staged columns, a multiple of 4.  Eight loads per lane are issued before
 // the first is used.
 template <bool SPECIAL>
-__device__ __forceinline__ void box_stage_tile_wide(uint16_t *t1, __amdgpu_buffer_rsrc_t rsrc, int N, int W, int x0, int y0,
-                                                    int a, int SH, int IWs, int IH, float w, const uint16_t *lut) {
+__device__ __forceinline__ uint32_t box_stage_tile_wide(uint16_t *t1, __amdgpu_buffer_rsrc_t rsrc, int N, int W, int x0, int y0,
+                                                        int a, int SH, int IWs, int IH, float w, const uint16_t *lut) {
     const int DW = IWs >> 2;
+    uint32_t seen = 0;
     const int tasks = IH * DW;
     // task t = (row t / DW, dword t % DW); a lane's tasks are 256 apart: one division, then steps
     const int step_r = 256 / DW, step_d = 256 - step_r * DW;
@@ -169,39 +176,22 @@ __device__ __forceinline__ void box_stage_tile_wide(uint16_t *t1, __amdgpu_buffe
                 uint32_t *q = reinterpret_cast<uint32_t *>(t1 + r * BX_PITCH + 4 * d);  // BX_PITCH is even
                 q[0] = e[0] | (e[1] << 16);
                 q[1] = e[2] | (e[3] << 16);
+                seen |= e[0] | e[1] | e[2] | e[3];
             }
             r += step_r; d += step_d;
             if (d >= DW) { d -= DW; r++; }
         }
         r0 = r; d0 = d;
     }
+    return seen;
 }
 
+// (B) and (C) of the plain box sum on a staged tile: t1 holds the elements (IW x IH, the tile's column 0 at
+// staged column sh), t2 receives the vertical sums.  keep: the bits of an element pair that belong to the value
+// (the special form's elements carry flags above them, which the vertical sums drop here).
 template <bool AVG>
-__global__ __launch_bounds__(256) void box_sum_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W, int H,
-                                                      long long in_stride, long long out_stride, int kW, int kH, float w,
-                                                      int divisor, int tiles_x, bool wide) {
-    __shared__ __attribute__((aligned(16))) uint16_t t1[BX_IN * BX_PITCH];  // floor(pixel * w)
-    __shared__ __attribute__((aligned(16))) uint16_t t2[BX_T * BX_PITCH];   // vertical sums
-    const int N = W * H;  // the launcher keeps W * (H + 32) below 2^31
-    const uint8_t *src = in + (long long)blockIdx.y * in_stride;
-    uint8_t *dst = out + (long long)blockIdx.y * out_stride;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
-    const int a = (kH - 1) / 2, s = (kW - 1) / 2;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int x0 = tx * BX_T, y0 = ty * BX_T;
-    int IW = BX_T + kW - 1;
-    const int IH = BX_T + kH - 1;
-    int sh = 0;  // tile column 0 (image column x0 - s) sits at staged column sh
-    if (wide) {
-        const int SH = (s + 3) & ~3;
-        sh = SH - s;
-        IW = (BX_T + SH + s + 3) & ~3;
-        box_stage_tile_wide<false>(t1, rsrc, N, W, x0, y0, a, SH, IW, IH, w, nullptr);
-    } else {
-        box_stage_tile<false>(t1, rsrc, N, W, x0, y0, a, s, IW, IH, w, nullptr);
-    }
-    __syncthreads();
+__device__ __forceinline__ void box_plain_passes(const uint16_t *t1, uint16_t *t2, uint8_t *dst, int W, int H, int x0, int y0,
+                                                 int IW, int kW, int kH, int a, int s, int sh, int divisor, uint32_t keep) {
     // (B) column pairs x four segments of 16 output rows: sliding sums of kH rows.  Two 16-bit
     // sums travel in one word; a carry from the low half into the high one during an add is
     // taken back by the subtraction that follows, since every finished sum fits 16 bits.
@@ -214,12 +204,12 @@ __global__ __launch_bounds__(256) void box_sum_kernel(const uint8_t *__restrict_
             const int r0 = seg * 16;
             uint32_t acc = 0;
             for (int i = 0; i < kH; i++) acc += col[(r0 + i) * (BX_PITCH / 2)];
-            dstc[r0 * (BX_PITCH / 2)] = acc;
+            dstc[r0 * (BX_PITCH / 2)] = acc & keep;
 #pragma unroll 4
             for (int y = 1; y < 16; y++) {
                 acc += col[(r0 + y + kH - 1) * (BX_PITCH / 2)];
                 acc -= col[(r0 + y - 1) * (BX_PITCH / 2)];
-                dstc[(r0 + y) * (BX_PITCH / 2)] = acc;
+                dstc[(r0 + y) * (BX_PITCH / 2)] = acc & keep;
             }
         }
     }
@@ -253,6 +243,34 @@ __global__ __launch_bounds__(256) void box_sum_kernel(const uint8_t *__restrict_
         for (int i = 0; i < 16; i++)
             if (col0 + i < W) qd[i] = (uint8_t)o[i];
     }
+}
+
+template <bool AVG>
+__global__ __launch_bounds__(256) void box_sum_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W, int H,
+                                                      long long in_stride, long long out_stride, int kW, int kH, float w,
+                                                      int divisor, int tiles_x, bool wide) {
+    __shared__ __attribute__((aligned(16))) uint16_t t1[BX_IN * BX_PITCH];  // floor(pixel * w)
+    __shared__ __attribute__((aligned(16))) uint16_t t2[BX_T * BX_PITCH];   // vertical sums
+    const int N = W * H;  // the launcher keeps W * (H + 32) below 2^31
+    const uint8_t *src = in + (long long)blockIdx.y * in_stride;
+    uint8_t *dst = out + (long long)blockIdx.y * out_stride;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
+    const int a = (kH - 1) / 2, s = (kW - 1) / 2;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * BX_T, y0 = ty * BX_T;
+    int IW = BX_T + kW - 1;
+    const int IH = BX_T + kH - 1;
+    int sh = 0;  // tile column 0 (image column x0 - s) sits at staged column sh
+    if (wide) {
+        const int SH = (s + 3) & ~3;
+        sh = SH - s;
+        IW = (BX_T + SH + s + 3) & ~3;
+        box_stage_tile_wide<false>(t1, rsrc, N, W, x0, y0, a, SH, IW, IH, w, nullptr);
+    } else {
+        box_stage_tile<false>(t1, rsrc, N, W, x0, y0, a, s, IW, IH, w, nullptr);
+    }
+    __syncthreads();
+    box_plain_passes<AVG>(t1, t2, dst, W, H, x0, y0, IW, kW, kH, a, s, sh, divisor, 0xffffffffu);
 }
 
 // The special form, rows first.  Per window the specials that earn nothing are those in front of
@@ -299,14 +317,23 @@ __global__ __launch_bounds__(256) void box_special_kernel(const uint8_t *__restr
     const int x0 = tx * BX_T, y0 = ty * BXS_TY;
     const int IW = BX_T + kW - 1, IH = BXS_TY + kH - 1;
     int sh = 0;  // tile column 0 (image column x0 - s) sits at staged column sh
+    int IWs = IW;  // staged columns
+    uint32_t seen;
     if (wide) {
         const int SH = (s + 3) & ~3;
         sh = SH - s;
-        box_stage_tile_wide<true>(t1, rsrc, N, W, x0, y0, a, SH, (BX_T + SH + s + 3) & ~3, IH, w, lut);
+        IWs = (BX_T + SH + s + 3) & ~3;
+        seen = box_stage_tile_wide<true>(t1, rsrc, N, W, x0, y0, a, SH, IWs, IH, w, lut);
     } else {
-        box_stage_tile<true>(t1, rsrc, N, W, x0, y0, a, s, IW, IH, w, lut);
+        seen = box_stage_tile<true>(t1, rsrc, N, W, x0, y0, a, s, IW, IH, w, lut);
     }
-    __syncthreads();
+    // A tile that holds no special value at all is a plain box sum of the floors: the two sliding passes of
+    // box_sum_kernel on the same elements (their flag bits dropped after the vertical sums, where they are
+    // still apart from the value's six).  Uniform over the workgroup.
+    if (!__syncthreads_or((int)(seen & 0x40u))) {
+        box_plain_passes<AVG>(t1, reinterpret_cast<uint16_t *>(t2), dst, W, H, x0, y0, IWs, kW, kH, a, s, sh, divisor, 0x003f003fu);
+        return;
+    }
     // (B) IH rows x 8 chunks of 8 outputs
     for (int task = threadIdx.x; task < IH * 8; task += 256) {
         const int r = task >> 3, c0 = (task & 7) << 3;
