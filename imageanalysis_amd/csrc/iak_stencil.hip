@@ -17,6 +17,7 @@
 #include "iak_morph_chain.hpp"
 #include "iak_morph_rows.hpp"
 #include "iak_median25.hpp"
+#include "iak_median_bits.hpp"
 
 namespace iak {
 
@@ -482,6 +483,10 @@ int iak_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long i
             op.rank = (uint32_t)(kernSum / 2);
             return launch8(in, out, W, H, B, in_stride, out_stride, op, stream);
         }
+    }
+    if (ones && kW * kH <= 49 && !getenv("IAK_NO_BITSLICE_MEDIAN")) {
+        rc = launch_bitslice_median(in, out, W, H, B, in_stride, out_stride, kW, kH, as_stream(stream));
+        if (rc != IAK_E_UNSUPPORTED) return rc;
     }
     if (ones && kW == 5 && kH == 5) {
         rc = launch_median25_rows(in, out, W, H, B, in_stride, out_stride, as_stream(stream));
