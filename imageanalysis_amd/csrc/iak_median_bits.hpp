@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KW * KH > 3
 #pragma unroll
         for (int i = 7; i > 0; i--) med[i] = med[i - 1];
         med[0] = lt;  // after the last level med[i] is the median's bit i
+        if (b == 0) break;  // the last bit is decided: nothing left to update
 #pragma unroll
         for (int i = 0; i < RW; i++) rank[i] = mb_op3<0xe4>(diff[i], rank[i], lt);  // lt ? diff : rank
 #pragma unroll

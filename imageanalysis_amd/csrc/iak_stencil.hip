@@ -16,7 +16,6 @@
 #include "iak_stencil_tiled.hpp"
 #include "iak_morph_chain.hpp"
 #include "iak_morph_rows.hpp"
-#include "iak_median25.hpp"
 #include "iak_median_bits.hpp"
 
 namespace iak {
@@ -486,10 +485,6 @@ int iak_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long i
     }
     if (ones && kW * kH <= 49 && !getenv("IAK_NO_BITSLICE_MEDIAN")) {
         rc = launch_bitslice_median(in, out, W, H, B, in_stride, out_stride, kW, kH, as_stream(stream));
-        if (rc != IAK_E_UNSUPPORTED) return rc;
-    }
-    if (ones && kW == 5 && kH == 5) {
-        rc = launch_median25_rows(in, out, W, H, B, in_stride, out_stride, as_stream(stream));
         if (rc != IAK_E_UNSUPPORTED) return rc;
     }
     if (ones) {
