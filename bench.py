@@ -37,7 +37,6 @@ def parse_args(argv=None):
                          "[1,1,1,10,1,1,1,1,1] (test/configs/input.json:43-53)")
     ap.add_argument("--stagewise", action="store_true", help="one pass per operation (no fusion)")
     ap.add_argument("--pointwise", action="store_true", help="fuse per-pixel runs only; stencils stay separate passes")
-    ap.add_argument("--strips", action="store_true", help="also fuse runs of 3x3 stencils through LDS strips")
     ap.add_argument("--lanes", type=int, default=1, help="concurrent sub-batches per GPU (executor streams)")
     ap.add_argument("--settle-ms", type=float, default=100.0,
                     help="run the pipeline untimed for this long before the warm-up steps (clock ramp after the idle "
@@ -135,7 +134,6 @@ P_A = p_a_ops()
 # launch group -> the HIP kernel that does its image pass (names as rocprofv3 prints them)
 KERNEL_OF_GROUP = {
     "gray+hist": "iak::gray_kernel<0, true>",
-    "equalize+gauss+salt_pepper+linear+median+sobel": "iak::strip_kernel",
     "equalize+gauss+salt_pepper+linear": "iak::lgs_stencil8_flat_kernel<iak::Lin8Swar>",
     "equalize+gauss+salt_pepper": "iak::chain_apply_kernel<false>",
     "linear": "iak::stencil8_kernel<iak::Lin8Swar, 8, false, false>",
@@ -561,7 +559,7 @@ class Measurement:
 
 
 def _mode_of(args):
-    return False if args.stagewise else ("pointwise" if args.pointwise else ("strips" if args.strips else True))
+    return False if args.stagewise else ("pointwise" if args.pointwise else True)
 
 
 def _threads(B):
@@ -642,7 +640,7 @@ def main():
                                     f"share, " if B == CONFIG3_IMAGES_PER_GPU and world > 1 else "") +
                                    f"batch of {B} {W}x{H} RGB cell-like images per GPU, {what}, device-resident",
                        "images_per_gpu": B, "settle_ms": args.settle_ms,
-                       "mode": "stagewise" if args.stagewise else ("fused-pointwise" if args.pointwise else ("fused-strips" if args.strips else "fused")),
+                       "mode": "stagewise" if args.stagewise else ("fused-pointwise" if args.pointwise else "fused"),
                        "lanes": args.lanes,
                        "parallelism": (f"image-wise shards x{world}, the {reduction} of every step all-reduced, "
                                        f"{args.reduce_every} steps' rows per collective" if m.dist is not None else

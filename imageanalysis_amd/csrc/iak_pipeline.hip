@@ -17,7 +17,6 @@
 #include "iak_hist.hpp"
 #include "iak_chain_stencil.hpp"
 #include "iak_binary_stencil.hpp"
-#include "iak_strip.hpp"
 #include "iak_stencil_ops.hpp"
 
 #include <new>
@@ -263,7 +262,7 @@ struct OpCopy {
     std::vector<int> i;
 };
 
-enum GroupKind { G_GRAYHIST, G_HIST, G_CHAIN, G_OP, G_CHAIN_OP, G_FEATURES, G_STRIP, G_MORPH };
+enum GroupKind { G_GRAYHIST, G_HIST, G_CHAIN, G_OP, G_CHAIN_OP, G_FEATURES, G_MORPH };
 
 struct Group {
     GroupKind kind;
@@ -271,9 +270,8 @@ struct Group {
     long long alg_bytes;  // algorithmic bytes per pixel of the operations in the group
     int op_index = -1;    // G_OP; G_MORPH: the first operation of the run
     int n_ops = 1;        // G_MORPH: operations in the run
-    ChainDesc chain;      // G_CHAIN, G_CHAIN_OP, G_STRIP (n == 0: no per-pixel run in front)
+    ChainDesc chain;      // G_CHAIN, G_CHAIN_OP; G_MORPH (n == 0: no threshold in front)
     bool chain_needs_hist = false;
-    StripDesc strip;      // G_STRIP
     bool emit_hist = false;  // G_CHAIN, G_OP: the pass also leaves the histogram of its output
     bool hist_from_tables = false;  // G_CHAIN of look-up stages only: that histogram comes from the table prologue
     bool hist_tracked = false;      // G_CHAIN: the prologue has the input's histogram and every stage carries it on
@@ -414,34 +412,6 @@ static void free_all(iak_pipeline *p) {
     for (auto e : p->ev) (void)hipEventDestroy(e);
     for (auto e : p->fork_join) (void)hipEventDestroy(e);
     for (auto st : p->aux) (void)hipStreamDestroy(st);
-}
-
-// A run of 3x3 stencils starting at operation i that one strip pass can take: at least two,
-// at most three, no dilation (see iak_strip.hpp).  Fills g->strip and returns the
-// number of operations taken, 0 if there is no such run.
-static int take_strip(const iak_pipeline *p, int i, Group *g) {
-    const int n = (int)p->ops.size();
-    if (p->mode != IAK_PIPE_FUSED_STRIPS || (long long)p->W * p->H >= (1LL << 30)) return 0;
-    int run = 0;
-    StripOp so[SK_MAX_STAGES];
-    while (i + run < n && run < SK_MAX_STAGES) {
-        const iak_op &o = p->ops[i + run].op;
-        if (!is_fusable_stencil(o) || o.type == IAK_OP_DILATE) break;
-        if (!strip_op_from(o, &so[run])) break;
-        run++;
-    }
-    while (run >= 2 && strip_rows(p->W, run) == 0) run--;
-    if (run < 2) return 0;
-    g->strip.S = run;
-    g->strip.TH = strip_rows(p->W, run);
-    g->strip.n = 4;
-    for (int k = 0; k < run; k++) {
-        g->strip.op[k] = so[k];
-        g->alg_bytes += op_alg_bytes(p->ops[i + k].op.type);
-        if (!g->name.empty()) g->name += "+";
-        g->name += op_name(p->ops[i + k].op.type);
-    }
-    return run;
 }
 
 // The 512 results of a 3x3 operation on 0 / 255 pixels, from the operation's own kernel run once
@@ -598,7 +568,7 @@ static int plan(iak_pipeline *p) {
             };
             const bool one_threshold = g.chain.n == 1 && (p->ops[i - 1].op.type == IAK_OP_OTSU ||
                                                           (p->ops[i - 1].op.type == IAK_OP_THRESHOLD && p->ops[i - 1].op.iparam >= 0));
-            if ((p->mode == IAK_PIPE_FUSED || p->mode == IAK_PIPE_FUSED_STRIPS) && one_threshold && i < n && is_morph3(i) &&
+            if (p->mode == IAK_PIPE_FUSED && one_threshold && i < n && is_morph3(i) &&
                 p->W % 16 == 0 && (long long)p->W * ((long long)p->H + 8) < (1LL << 30)) {
                 int run = 0;
                 while (i + run < n && run < 3 && is_morph3(i + run)) run++;
@@ -611,13 +581,8 @@ static int plan(iak_pipeline *p) {
                 }
                 i += run;
             } else
-            // a run of stencils right after the chain: one strip pass for the chain and all of them
-            if (const int taken = take_strip(p, i, &g)) {
-                g.kind = G_STRIP;
-                i += taken;
-            } else
             // a single stencil right after the chain reads the chain's output from LDS instead of memory
-            if ((p->mode == IAK_PIPE_FUSED || p->mode == IAK_PIPE_FUSED_STRIPS) && i < n && p->W % 16 == 0 && (long long)p->W * p->H < (1LL << 30) && is_fusable_stencil(p->ops[i].op)) {
+            if (p->mode == IAK_PIPE_FUSED && i < n && p->W % 16 == 0 && (long long)p->W * p->H < (1LL << 30) && is_fusable_stencil(p->ops[i].op)) {
                 g.kind = G_CHAIN_OP;
                 g.op_index = i;
                 // one threshold (fixed and not negative, or Otsu) in front of an operation that zeroes
@@ -639,20 +604,8 @@ static int plan(iak_pipeline *p) {
             hist_known = false;  // conservative: a later consumer re-measures
             continue;
         }
-        {
-            Group gs;
-            gs.alg_bytes = 0;
-            gs.chain.n = 0;
-            if (const int taken = take_strip(p, i, &gs)) {
-                gs.kind = G_STRIP;
-                p->groups.push_back(gs);
-                hist_known = false;
-                i += taken;
-                continue;
-            }
-        }
         // a run of 3x3 erosions / dilations is one pass on bit masks
-        if ((p->mode == IAK_PIPE_FUSED || p->mode == IAK_PIPE_FUSED_STRIPS) && p->W % 8 == 0 &&
+        if (p->mode == IAK_PIPE_FUSED && p->W % 8 == 0 &&
             (long long)p->W * ((long long)p->H + 8) < (1LL << 30)) {
             auto is_morph3 = [&](int k) {
                 const iak_op &q = p->ops[k].op;
@@ -732,9 +685,7 @@ extern "C" {
 int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op *ops, int nops,
                         unsigned long long seed, int mode) {
     if (!out || W <= 0 || H <= 0 || maxB <= 0 || nops < 0 || (nops > 0 && !ops)) return IAK_E_ARG;
-    if (mode != IAK_PIPE_STAGEWISE && mode != IAK_PIPE_FUSED && mode != IAK_PIPE_FUSED_POINTWISE &&
-        mode != IAK_PIPE_FUSED_STRIPS)
-        return IAK_E_ARG;
+    if (mode != IAK_PIPE_STAGEWISE && mode != IAK_PIPE_FUSED && mode != IAK_PIPE_FUSED_POINTWISE) return IAK_E_ARG;
     iak_pipeline *p = new (std::nothrow) iak_pipeline();
     if (!p) return (int)hipErrorOutOfMemory;
     p->W = W; p->H = H; p->maxB = maxB; p->mode = mode;
@@ -1113,30 +1064,6 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
             cur_hist = nullptr;
             break;
         }
-        case G_STRIP: {
-            const ChainDesc cd = chain_for(p, g.chain, b0);
-            if (cd.n) {
-                bool wants = false;
-                for (int k = 0; k < cd.n; k++)
-                    wants = wants || cd.st[k].type == C_EQUALIZE || cd.st[k].type == C_OTSU || cd.st[k].type == C_KMEANS ||
-                            (cd.st[k].type == C_GAUSS && (cd.st[k].mean == -1 || cd.st[k].stddev == -1));
-                if (wants && !cur_hist) return IAK_E_UNSUPPORTED;  // planner invariant
-                for (int k = 0; k < cd.n; k++)
-                    if (cd.st[k].plane && cd.st[k].type != C_KMEANS && !aligned16(cd.st[k].plane)) return IAK_E_UNSUPPORTED;
-                launch_prep(cd, nullptr);
-                IAK_LAUNCH_CHECK();
-                if (ev) {
-                    p->split[gi] = 1;
-                    IAK_HIP(hipEventRecord(ev[2 * gi + 1], s));
-                }
-            } else if (ev) {
-                p->split[gi] = 0;
-            }
-            if (!aligned16(cur) || (reinterpret_cast<uintptr_t>(dst) & 7u)) return IAK_E_UNSUPPORTED;
-            rc = launch_strip(cur, dst, p->W, p->H, B, N, N, cd, sl.tables, g.strip, s);
-            cur_hist = nullptr;
-            break;
-        }
         case G_FEATURES:
             if (!p->features_out) return IAK_E_ARG;
             rc = iak_features(cur, p->W, p->H, B, N, cur_hist, p->features_out + (size_t)b0 * IAK_N_FEATURES,
@@ -1210,7 +1137,7 @@ static long long group_moved_bytes(const iak_pipeline *p, const Group &g) {
     switch (g.kind) {
     case G_GRAYHIST: return p->input <= IAK_INPUT_AVERAGE ? 4 : 2;
     case G_HIST: case G_FEATURES: return 1;
-    case G_CHAIN: case G_CHAIN_OP: case G_STRIP: case G_MORPH: return 2;
+    case G_CHAIN: case G_CHAIN_OP: case G_MORPH: return 2;
     case G_OP: {
         const iak_op &o = p->ops[g.op_index].op;
         return 2 + ((needs_hist(o) && !g.emit_hist) ? 1 : 0);  // stage-wise: a counting pass of its own first

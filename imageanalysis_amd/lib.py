@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("IAK_LIBRARY") or os.path.join(_HERE, "lib", "libiak.s
 
 IAK_E_ARG, IAK_E_UNSUPPORTED, IAK_E_TOO_LARGE = -1, -2, -3
 IAK_LINEAR_CLAMP, IAK_LINEAR_AVERAGE = 0, 1
-IAK_PIPE_STAGEWISE, IAK_PIPE_FUSED, IAK_PIPE_FUSED_POINTWISE, IAK_PIPE_FUSED_STRIPS = 0, 1, 2, 3
+IAK_PIPE_STAGEWISE, IAK_PIPE_FUSED, IAK_PIPE_FUSED_POINTWISE = 0, 1, 2
 (IAK_OP_EQUALIZE, IAK_OP_GAUSS, IAK_OP_SALT_PEPPER, IAK_OP_LINEAR, IAK_OP_AVERAGE, IAK_OP_MEDIAN, IAK_OP_SOBEL,
  IAK_OP_COMPASS, IAK_OP_DILATE, IAK_OP_ERODE, IAK_OP_THRESHOLD, IAK_OP_OTSU, IAK_OP_QUANTIZE, IAK_OP_KMEANS,
  IAK_OP_FEATURES) = range(1, 16)

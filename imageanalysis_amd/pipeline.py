@@ -53,8 +53,7 @@ def ops_from_config(operations):
 class Pipeline:
     """Owns an iak_pipeline.  ops: list of dicts with keys type, kW, kH, fkernel, ikernel,
     iparam, mean, stddev (same meaning as iak_op).  fused: True (per-pixel runs fused, and fed
-    straight into the 3x3 stencil behind them), "pointwise" (per-pixel runs fused only),
-    "strips" (as True, and runs of 3x3 stencils share one pass through LDS strips) or False (one
+    straight into the 3x3 stencil behind them), "pointwise" (per-pixel runs fused only) or False (one
     pass per operation)."""
 
     def __init__(self, W, H, maxB, ops, seed=1234, fused=True, device=None):
@@ -79,8 +78,7 @@ class Pipeline:
             arr[i].stddev = o.get("stddev", -1.0)
         self._h = C.c_void_p()
         L = _l.load()
-        mode = (_l.IAK_PIPE_FUSED_STRIPS if fused == "strips" else
-                _l.IAK_PIPE_FUSED_POINTWISE if fused == "pointwise" else
+        mode = (_l.IAK_PIPE_FUSED_POINTWISE if fused == "pointwise" else
                 _l.IAK_PIPE_FUSED if fused else _l.IAK_PIPE_STAGEWISE)
         _l.check(L.iak_pipeline_create(C.byref(self._h), self.W, self.H, self.maxB, arr, len(ops), seed, mode),
                  "iak_pipeline_create")

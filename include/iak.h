@@ -272,9 +272,6 @@ typedef struct {
 #define IAK_PIPE_STAGEWISE 0 /* one launch (or more) per operation, every intermediate image written */
 #define IAK_PIPE_FUSED 1     /* runs of per-pixel operations share one pass, and that pass also feeds the 3x3 stencil behind it */
 #define IAK_PIPE_FUSED_POINTWISE 2 /* as FUSED, but every stencil stays a pass of its own */
-#define IAK_PIPE_FUSED_STRIPS 3    /* as FUSED, and runs of two or three 3x3 stencils (no dilation) share one pass through
-                                    * LDS strips.  Identical results; on MI355X slower than FUSED for the stencils measured
-                                    * (they are instruction-bound, not bandwidth-bound), so it is not the default. */
 #define IAK_PIPE_MAX_STAGES 64
 
 typedef struct iak_pipeline iak_pipeline;

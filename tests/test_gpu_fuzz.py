@@ -10,7 +10,7 @@ import synth
 
 pytestmark = pytest.mark.gpu
 
-MODES = [False, "pointwise", True, "strips"]
+MODES = [False, "pointwise", True]
 
 
 def random_op(rs):

@@ -66,7 +66,7 @@ CHAINS = {
                       {"type": O.OP_AVERAGE, "kW": 3, "kH": 3, "fkernel": [1.0] * 9},
                       {"type": O.OP_THRESHOLD, "iparam": 90},
                       {"type": O.OP_LINEAR, "kW": 3, "kH": 3, "fkernel": [0.3, -0.2, 0.1, 0.7, 1.1, -0.4, 0.25, 0.05, 0.6]}],
-    # runs of 3x3 stencils (one strip pass for up to three of them; dilations stay on their own)
+    # runs of 3x3 stencils
     "median+sobel": [{"type": O.OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": ONES9}, {"type": O.OP_SOBEL}],
     "dilate+erode+compass+median+sobel": [
         {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": ONES9}, {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": CROSS},
@@ -121,7 +121,7 @@ def Pipeline():
 
 
 @pytest.mark.parametrize("name", list(CHAINS))
-@pytest.mark.parametrize("fused", [False, "pointwise", True, "strips"])
+@pytest.mark.parametrize("fused", [False, "pointwise", True])
 @pytest.mark.parametrize("W,H,kind", [(64, 48, "C"), (37, 23, "U"), (768, 40, "C"), (48, 203, "U"), (1056, 21, "U"),
                                       (16, 9, "U"), (1024, 43, "U"), (2048, 5, "C"), (8, 11, "U"), (40, 8, "C")])
 def test_pipeline_matches_oracle(Pipeline, name, fused, W, H, kind):
@@ -228,11 +228,9 @@ def test_pipeline_timings(Pipeline):
     t = p.timings(1)
     names = [r[0] for r in t]
     assert names == ["gray+hist", "equalize+gauss+salt_pepper+linear", "median", "sobel"]
-    assert [n for n, _ in Pipeline(W, H, 2, P_A, fused="strips").groups()] == [
-        "gray+hist", "equalize+gauss+salt_pepper+linear+median+sobel"]
     assert [n for n, _ in Pipeline(W, H, 2, P_A, fused="pointwise").groups()][1:3] == ["equalize+gauss+salt_pepper", "linear"]
-    # a width the strips do not take (not a multiple of 16) keeps one pass per stencil
-    assert [n for n, _ in Pipeline(40, H, 2, P_A, fused="strips").groups()][1:] == [
+    # a width the fused chain + stencil pass does not take (not a multiple of 16) keeps one pass per stencil
+    assert [n for n, _ in Pipeline(40, H, 2, P_A, fused=True).groups()][1:] == [
         "equalize+gauss+salt_pepper", "linear", "median", "sobel"]
     assert sum(r[2] for r in t) == 19  # stage-wise compulsory bytes per pixel of this pipeline
     assert all(r[1] >= 0 and 0 <= r[3] <= r[1] + 1e-3 for r in t)
@@ -258,7 +256,7 @@ KM_CHAINS = {
 
 
 @pytest.mark.parametrize("name", list(KM_CHAINS))
-@pytest.mark.parametrize("fused", [False, "pointwise", True, "strips"])
+@pytest.mark.parametrize("fused", [False, "pointwise", True])
 @pytest.mark.parametrize("W,H,kind,lanes", [(64, 48, "C", 1), (37, 23, "U", 1), (768, 40, "C", 3)])
 def test_pipeline_kmeans_and_features(Pipeline, name, fused, W, H, kind, lanes):
     """k-means draws its centroids from the libc rand() stream, two per image per k-means

@@ -32,7 +32,7 @@ if args and args[0] == "--size":
 rgb = bench.make_cell_batch(B, torch.device("cuda"), 1)
 out = torch.empty((B, bench.H, bench.W), dtype=torch.uint8, device="cuda")
 for name in args:
-    for mode in [False, "pointwise", True, "strips"]:
+    for mode in [False, "pointwise", True]:
         p = Pipeline(bench.W, bench.H, B, CASES[name], fused=mode)
         p.bind_features(torch.zeros((B, 7), dtype=torch.float32, device="cuda"))
         for _ in range(3):
