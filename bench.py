@@ -144,7 +144,7 @@ KERNEL_OF_GROUP = {
 KERNEL_OF_GROUP_BY_WORKLOAD = {
     "P-A/config": {"equalize+gauss+salt_pepper+linear": "iak::lgs_stencil8_flat_kernel<iak::Lin8Pk16<false> >",
                    "linear": "iak::stencil8_kernel<iak::Lin8Pk16<false>, 8, false, false>"},
-    "P-B": {"linear": "iak::box_special_kernel<false, 11>", "median": "iak::column_hist_median_kernel<7, 2>"},
+    "P-B": {"linear": "iak::box_special_kernel<false, 11>", "median": "iak::bitslice_median_kernel<7, 7>"},
     "P-C": {"otsu": "iak::chain_apply_kernel<false>", "otsu+sobel": "iak::binary_table_stencil_kernel",
             "dilate+erode+hist": "iak::morph_chain_kernel<2, 2, false>", "features": "iak::perimeter_bits_kernel"},
 }
@@ -490,7 +490,7 @@ class Measurement:
         # Counter figures are not measured in this run: they come from the committed summaries of earlier rocprofv3
         # --pmc passes (tools/profile_round.sh) and are used only where the kernel's name and the batch are the
         # same as in this run; otherwise the field is left out (null in `roofline`).
-        traffic = _load_profile_json("traffic.json")
+        traffic = _load_profile_json("traffic.json" if B == WORKLOADS[self.name][3] else f"traffic_B{B}.json")
         valu_all = _load_profile_json("valu.json")
         valu = valu_all.get(variant or self.name, {})
         valu_batch = WORKLOADS[self.name][3]  # the counter passes run the workload's default batch
@@ -531,7 +531,8 @@ class Measurement:
             "pipeline_hbm_frac_moved_bytes": round(value * 1e6 / world * moved_total / (HBM_PEAK_GBS * 1e9), 4),
             "pipeline_stagewise_bytes_per_px": self.stagewise_bytes,
             "intermediates_llc_resident": bool(llc),
-            "traffic_source": f"profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, batch {B})" if used_traffic else None,
+            "traffic_source": (f"profiles/{'traffic.json' if B == WORKLOADS[self.name][3] else f'traffic_B{B}.json'} "
+                               f"(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, batch {B})") if used_traffic else None,
             "valu_source": f"profiles/valu.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU pass, batch {valu_batch})" if used_valu else None,
             "groups": groups,
         }

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/iak.h"
 
 #define IAK_HIP(call)                          \
@@ -20,6 +22,10 @@
     } while (0)
 
 namespace iak {
+
+// iak_set_contraction's switch (iak_host.cpp): the reference's a * b + c expressions as fused multiply-adds
+extern std::atomic<int> g_contraction;
+static inline bool contraction() { return g_contraction.load() != 0; }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 

@@ -112,6 +112,8 @@ __device__ inline uint16_t gauss_entry(int rv, float mean, float variance) {
 
 
 // curand_uniform: x * 2^-32 + 2^-33 as two float operations
+// (2.3283064e-10f is 2^-32 exactly, so the product is exact and a compiler that fuses the two operations --
+// nvcc by default -- gets the same bits)
 __device__ __forceinline__ float xw_uniform(uint32_t x) {
     float f = (float)x * 2.3283064e-10f;
     return f + (2.3283064e-10f / 2.0f);

@@ -2,11 +2,23 @@
 // helpers that stand in for cudaMalloc / cudaMemcpy / cudaFree in a host program.
 #include "iak_common.hpp"
 
+#include <atomic>
+
 using namespace iak;
+
+namespace iak {
+std::atomic<int> g_contraction{0};
+}
 
 extern "C" {
 
 int iak_version(void) { return 100; }
+
+int iak_set_contraction(int enabled) {
+    iak::g_contraction.store(enabled ? 1 : 0);
+    return 0;
+}
+int iak_get_contraction(void) { return iak::g_contraction.load(); }
 
 const char *iak_error_string(int code) {
     switch (code) {

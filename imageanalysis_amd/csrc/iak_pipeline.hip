@@ -242,7 +242,9 @@ __global__ __launch_bounds__(256) void hist_accumulate_kernel(const uint32_t *__
 
 namespace iak {
 int stencil3_with_hist(const iak_op &o, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
-                       long long out_stride, uint32_t *hist, void *stream, bool hist_cleared);  // iak_stencil.hip
+                       long long out_stride, uint32_t *hist, void *stream, bool hist_cleared, bool fused);  // iak_stencil.hip
+int linear_with_contraction(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
+                            const float *kernel, int kW, int kH, int mode, bool fused, void *stream);  // iak_stencil.hip
 int morph_chain3(const iak_op *ops, int n, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
                  long long out_stride, uint32_t *hist, const uint16_t *tables, void *stream, bool hist_cleared);  // iak_stencil.hip
 // iak_gray_hist / iak_channel_hist (method 2) into a histogram the caller has cleared already
@@ -326,6 +328,7 @@ long long op_alg_bytes(int t) {
 #define HIST_RING 8
 struct iak_pipeline {
     int W = 0, H = 0, maxB = 0, mode = 0;
+    bool fused_math = false;  // contraction mode as it was when the pipeline was created (iak_set_contraction)
     int input = IAK_INPUT_LUMINANCE;
     long long N = 0;
     std::vector<OpCopy> ops;
@@ -689,6 +692,7 @@ int iak_pipeline_create(iak_pipeline **out, int W, int H, int maxB, const iak_op
     iak_pipeline *p = new (std::nothrow) iak_pipeline();
     if (!p) return (int)hipErrorOutOfMemory;
     p->W = W; p->H = H; p->maxB = maxB; p->mode = mode;
+    p->fused_math = contraction();
     p->N = (long long)W * H;
     bool any_noise = false;
     for (int i = 0; i < nops; i++) {
@@ -887,8 +891,8 @@ static int run_single_op(iak_pipeline *p, const Slice &sl, const iak_op &o, cons
         return iak_gauss_noise(src, dst, N, B, N, N, p->rv, sl.tables, from_image ? 256 : 0, stream);
     }
     case IAK_OP_SALT_PEPPER: return iak_salt_pepper(src, dst, N, B, N, N, p->sp_plane(o.iparam), stream);
-    case IAK_OP_LINEAR: return iak_linear(src, dst, W, H, B, N, N, o.fkernel, o.kW, o.kH, IAK_LINEAR_CLAMP, stream);
-    case IAK_OP_AVERAGE: return iak_linear(src, dst, W, H, B, N, N, o.fkernel, o.kW, o.kH, IAK_LINEAR_AVERAGE, stream);
+    case IAK_OP_LINEAR: return linear_with_contraction(src, dst, W, H, B, N, N, o.fkernel, o.kW, o.kH, IAK_LINEAR_CLAMP, p->fused_math, stream);
+    case IAK_OP_AVERAGE: return linear_with_contraction(src, dst, W, H, B, N, N, o.fkernel, o.kW, o.kH, IAK_LINEAR_AVERAGE, p->fused_math, stream);
     case IAK_OP_MEDIAN: return iak_median(src, dst, W, H, B, N, N, o.ikernel, o.kW, o.kH, stream);
     case IAK_OP_SOBEL: return iak_sobel(src, dst, W, H, B, N, N, stream);
     case IAK_OP_COMPASS: return iak_compass(src, dst, W, H, B, N, N, stream);
@@ -976,12 +980,15 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
         case G_GRAYHIST:
             if (!gray_hist)  // the executor's own table: cleared ahead of time (iak_pipeline_run)
                 rc = p->input <= IAK_INPUT_AVERAGE
-                         ? gray_hist_cleared(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input, s)
+                         ? gray_hist_cleared(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, (p->input == IAK_INPUT_LUMINANCE && p->fused_math) ? 3 : p->input, s)
                          : gray_hist_cleared(rgb + (long long)(p->input - IAK_INPUT_RED) * N, dst, ghist, p->W, p->H, B, 3 * N, N, 2, s);
-            else
-                rc = p->input <= IAK_INPUT_AVERAGE
-                         ? iak_gray_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input, s)
-                         : iak_channel_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input - IAK_INPUT_RED, s);
+            else if (p->input <= IAK_INPUT_AVERAGE) {
+                rc = (int)hipMemsetAsync(ghist, 0, sizeof(uint32_t) * 256 * (size_t)B, s);  // the caller's array: cleared per run
+                if (rc == 0)
+                    rc = gray_hist_cleared(rgb, dst, ghist, p->W, p->H, B, 3 * N, N,
+                                           (p->input == IAK_INPUT_LUMINANCE && p->fused_math) ? 3 : p->input, s);
+            } else
+                rc = iak_channel_hist(rgb, dst, ghist, p->W, p->H, B, 3 * N, N, p->input - IAK_INPUT_RED, s);
             if (ev) p->split[gi] = 0;
             // the data-set histogram is folded by the next table prologue's spare workgroups, or at the end
             pending_sum = rc == 0 ? hist_sum : nullptr;
@@ -1052,8 +1059,8 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
                 return launch_chain_stencil(cur, dst, p->W, p->H, B, N, N, cd, sl.tables, op, s);
             };
             switch (o.type) {
-            case IAK_OP_LINEAR: rc = with_linear3_op<false>(o.fkernel, go); break;
-            case IAK_OP_AVERAGE: rc = with_linear3_op<true>(o.fkernel, go); break;
+            case IAK_OP_LINEAR: rc = with_linear3_op<false>(o.fkernel, go, p->fused_math); break;
+            case IAK_OP_AVERAGE: rc = with_linear3_op<true>(o.fkernel, go, p->fused_math); break;
             case IAK_OP_MEDIAN: rc = go(Median8()); break;
             case IAK_OP_SOBEL: rc = go(Sobel8()); break;
             case IAK_OP_COMPASS: rc = go(Compass8()); break;
@@ -1104,7 +1111,7 @@ static int run_range(iak_pipeline *p, const uint8_t *rgb, uint8_t *out, int b0, 
         }
         case G_OP:
             if (g.emit_hist) {
-                rc = stencil3_with_hist(p->ops[g.op_index].op, cur, dst, p->W, p->H, B, N, N, sl.hist2, s, take_hist2());
+                rc = stencil3_with_hist(p->ops[g.op_index].op, cur, dst, p->W, p->H, B, N, N, sl.hist2, s, take_hist2(), p->fused_math);
                 if (rc == IAK_E_UNSUPPORTED) {  // buffers not aligned for the 8-pixel path: two passes
                     rc = run_single_op(p, sl, p->ops[g.op_index].op, cur, dst, B, nullptr, s);
                     if (rc == 0) rc = iak_hist(dst, sl.hist2, N, B, N, s);

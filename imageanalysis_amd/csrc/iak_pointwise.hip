@@ -163,6 +163,11 @@ __device__ __forceinline__ uint32_t lum1(uint32_t r, uint32_t g, uint32_t b) {
     double y = (.21 * (double)r + .72 * (double)g) + .07 * (double)b;
     return (uint32_t)(int)y;
 }
+// the same expression as nvcc's default -fmad=true compiles it: two fused multiply-adds (iak_set_contraction)
+__device__ __forceinline__ uint32_t lum1_fused(uint32_t r, uint32_t g, uint32_t b) {
+    double y = __builtin_fma(.07, (double)b, __builtin_fma(.21, (double)r, .72 * (double)g));
+    return (uint32_t)(int)y;
+}
 __device__ __forceinline__ uint32_t avg1(uint32_t r, uint32_t g, uint32_t b) { return (r + g + b) / 3u; }
 
 template <int METHOD>
@@ -170,8 +175,9 @@ __device__ __forceinline__ uint32_t gray4(uint32_t r, uint32_t g, uint32_t b) {
     uint32_t o = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        uint32_t y = METHOD == 0 ? lum1(byte_of(r, k), byte_of(g, k), byte_of(b, k))
-                                 : avg1(byte_of(r, k), byte_of(g, k), byte_of(b, k));
+        uint32_t y = METHOD == 0   ? lum1(byte_of(r, k), byte_of(g, k), byte_of(b, k))
+                     : METHOD == 3 ? lum1_fused(byte_of(r, k), byte_of(g, k), byte_of(b, k))
+                                   : avg1(byte_of(r, k), byte_of(g, k), byte_of(b, k));
         if (METHOD == 2) y = byte_of(r, k);  // one plane as it is (the G and B loads are dead code)
         o |= (y & 0xffu) << (8 * k);
     }
@@ -236,7 +242,7 @@ void gray_kernel(const uint8_t *__restrict__ rgb, uint8_t *__restrict__ gray, ui
     }
     const long long scalar_from = nchunks << 4;
     for (long long t = scalar_from + tid; t < N; t += nthreads) {
-        uint32_t y = METHOD == 2 ? R[t] : (METHOD == 0 ? lum1(R[t], G[t], Bp[t]) : avg1(R[t], G[t], Bp[t]));
+        uint32_t y = METHOD == 2 ? R[t] : (METHOD == 0 ? lum1(R[t], G[t], Bp[t]) : (METHOD == 3 ? lum1_fused(R[t], G[t], Bp[t]) : avg1(R[t], G[t], Bp[t])));
         dst[t] = (uint8_t)y;
         if (HIST) atomicAdd(&sh[(y & 0xff) * HIST_COLS + col], 1u);
     }
@@ -324,7 +330,8 @@ using namespace iak;
 
 extern "C" {
 
-// method 0 / 1: the two grayscale conversions; 2: the plane at `rgb` copied as it is
+// method 0 / 1: the two grayscale conversions; 2: the plane at `rgb` copied as it is; 3: method 0 with fused
+// multiply-adds (contraction mode)
 static int gray_launch(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B, long long rgb_stride,
                        long long gray_stride, int method, void *stream, bool hist_cleared = false) {
     const long long N = (long long)W * H;
@@ -342,12 +349,14 @@ static int gray_launch(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W,
 #define GH(M) hipLaunchKernelGGL((gray_kernel<M, true>), grid, block, 0, s, rgb, gray, hist, N, rgb_stride, gray_stride)
         if (method == 0) GH(0);
         else if (method == 1) GH(1);
+        else if (method == 3) GH(3);
         else GH(2);
 #undef GH
     } else {
 #define GN(M) hipLaunchKernelGGL((gray_kernel<M, false>), grid, block, 0, s, rgb, gray, (uint32_t *)nullptr, N, rgb_stride, gray_stride)
         if (method == 0) GN(0);
         else if (method == 1) GN(1);
+        else if (method == 3) GN(3);
         else GN(2);
 #undef GN
     }
@@ -361,7 +370,7 @@ int iak_gray_hist(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int 
     if (method != 0 && method != 1) return IAK_E_ARG;
     const long long N = (long long)W * H;
     if (rgb_stride < 3 * N || gray_stride < N) return IAK_E_ARG;
-    return gray_launch(rgb, gray, hist, W, H, B, rgb_stride, gray_stride, method, stream);
+    return gray_launch(rgb, gray, hist, W, H, B, rgb_stride, gray_stride, (method == 0 && contraction()) ? 3 : method, stream);
 }
 
 int iak_channel_hist(const uint8_t *rgb, uint8_t *out, uint32_t *hist, int W, int H, int B, long long rgb_stride,
@@ -459,7 +468,7 @@ namespace iak {
 // histogram table has been cleared ahead of time: no clear here.
 int gray_hist_cleared(const uint8_t *rgb, uint8_t *gray, uint32_t *hist, int W, int H, int B, long long rgb_stride,
                       long long gray_stride, int method, void *stream) {
-    if (!rgb || !gray || !hist || W <= 0 || H <= 0 || B <= 0 || method < 0 || method > 2) return IAK_E_ARG;
+    if (!rgb || !gray || !hist || W <= 0 || H <= 0 || B <= 0 || method < 0 || method > 3) return IAK_E_ARG;
     return gray_launch(rgb, gray, hist, W, H, B, rgb_stride, gray_stride, method, stream, true);
 }
 }  // namespace iak

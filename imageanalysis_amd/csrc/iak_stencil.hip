@@ -25,15 +25,22 @@ namespace iak {
 // =======================================================================================
 enum { G_LINEAR = 0, G_AVERAGE = 1, G_ERODE = 2, G_DILATE = 3, G_COMPASS = 4, G_SOBEL = 5 };
 
+// fused: each tap as one fused multiply-add (contraction mode)
 __device__ __forceinline__ int accumulate(const uint8_t *img, long long N, int W, int row, int col, int a, int s,
-                                          const float *k) {
+                                          const float *k, bool fused = false) {
     // imageAnalysis.cu:517-524: `int sum; sum += uchar * float` truncates at every tap
     int sum = 0;
     int n = 0;
     for (int i = row - a; i <= row + a; i++)
         for (int j = col - s; j <= col + s; j++) {
-            float prod = (float)tap_at(img, N, (long long)i * W + j) * k[n];
-            float acc = (float)sum + prod;
+            const float px = (float)tap_at(img, N, (long long)i * W + j);
+            float acc;
+            if (fused) {
+                acc = __builtin_fmaf(px, k[n], (float)sum);
+            } else {
+                float prod = px * k[n];
+                acc = (float)sum + prod;
+            }
             sum = (int)acc;
             n++;
         }
@@ -43,7 +50,7 @@ __device__ __forceinline__ int accumulate(const uint8_t *img, long long N, int W
 template <int MODE>
 __global__ __launch_bounds__(256) void generic_float_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                             int W, int H, long long in_stride, long long out_stride,
-                                                            int kW, int kH, Taps taps) {
+                                                            int kW, int kH, Taps taps, bool fused = false) {
     const long long N = (long long)W * H;
     const uint8_t *src = in + (long long)blockIdx.y * in_stride;
     uint8_t *dst = out + (long long)blockIdx.y * out_stride;
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256) void generic_float_kernel(const uint8_t *__res
         const int row = (int)(t / W), col = (int)(t - (long long)row * W);
         uint32_t o = 0;
         if (!is_border(row, col, W, H, a, s)) {
-            int sum = accumulate(src, N, W, row, col, a, s, taps.f);
+            int sum = accumulate(src, N, W, row, col, a, s, taps.f, fused);
             if (MODE == G_LINEAR) {
                 sum = sum > 255 ? 255 : (sum < 0 ? 0 : sum);
                 o = (uint32_t)sum;
@@ -367,18 +374,20 @@ static dim3 generic_grid(int W, int H, int B) { return dim3(blocks_x((long long)
 // The 3x3 operations of the 8-pixel path with the output's histogram as a by-product, for the
 // executor (not part of the C ABI).  IAK_E_UNSUPPORTED when the operation or the buffers do not
 // qualify; the caller then runs the operation and a histogram pass separately.
+int linear_with_contraction(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
+                            const float *kernel, int kW, int kH, int mode, bool fused, void *stream);
 int stencil3_with_hist(const iak_op &o, const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride,
-                       long long out_stride, uint32_t *hist, void *stream, bool hist_cleared) {
+                       long long out_stride, uint32_t *hist, void *stream, bool hist_cleared, bool fused) {
     if (check_image_args(in, out, W, H, B, in_stride, out_stride) || !hist) return IAK_E_ARG;
     if (!fast8_ok(in, out, W, H, in_stride, out_stride)) return IAK_E_UNSUPPORTED;
     auto go = [&](const auto &op) { return launch8(in, out, W, H, B, in_stride, out_stride, op, stream, hist, hist_cleared); };
     switch (o.type) {
     case IAK_OP_LINEAR:
         if (o.kW != 3 || o.kH != 3) return IAK_E_UNSUPPORTED;
-        return with_linear3_op<false>(o.fkernel, go);
+        return with_linear3_op<false>(o.fkernel, go, fused);
     case IAK_OP_AVERAGE:
         if (o.kW != 3 || o.kH != 3) return IAK_E_UNSUPPORTED;
-        return with_linear3_op<true>(o.fkernel, go);
+        return with_linear3_op<true>(o.fkernel, go, fused);
     case IAK_OP_MEDIAN:
         if (o.kW != 3 || o.kH != 3) return IAK_E_UNSUPPORTED;
         for (int i = 0; i < 9; i++)
@@ -429,6 +438,14 @@ extern "C" {
 
 int iak_linear(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
                const float *kernel, int kW, int kH, int mode, void *stream) {
+    return iak::linear_with_contraction(in, out, W, H, B, in_stride, out_stride, kernel, kW, kH, mode, contraction(), stream);
+}
+
+}  // extern "C"
+
+// iak_linear with the contraction setting as an argument (a pipeline keeps the one it was created under)
+int iak::linear_with_contraction(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
+                                 const float *kernel, int kW, int kH, int mode, bool fused, void *stream) {
     int rc = check_image_args(in, out, W, H, B, in_stride, out_stride);
     if (rc) return rc;
     if (!kernel || kW < 1 || kH < 1) return IAK_E_ARG;
@@ -436,25 +453,30 @@ int iak_linear(const uint8_t *in, uint8_t *out, int W, int H, int B, long long i
     if ((long long)kW * kH > IAK_MAX_TAPS) return IAK_E_TOO_LARGE;
     if (kW == 3 && kH == 3 && fast8_ok(in, out, W, H, in_stride, out_stride)) {
         auto go = [&](const auto &op) { return launch8(in, out, W, H, B, in_stride, out_stride, op, stream); };
-        return mode == IAK_LINEAR_AVERAGE ? with_linear3_op<true>(kernel, go) : with_linear3_op<false>(kernel, go);
+        return mode == IAK_LINEAR_AVERAGE ? with_linear3_op<true>(kernel, go, fused) : with_linear3_op<false>(kernel, go, fused);
     }
     // taps actually visited are (2a+1) x (2s+1), indexed consecutively (imageAnalysis.cu:518-523)
     Taps t;
     const int a = (kH - 1) / 2, s = (kW - 1) / 2;
     const int visited = (2 * a + 1) * (2 * s + 1);
     for (int i = 0; i < visited; i++) t.f[i] = kernel[i];
-    rc = launch_tiled_linear(in, out, W, H, B, in_stride, out_stride, 2 * s + 1, 2 * a + 1, kW * kH,
-                             mode == IAK_LINEAR_AVERAGE, t, as_stream(stream));
-    if (rc != IAK_E_UNSUPPORTED) return rc;
+    // the tiled, row and box kernels are built on the unfused accumulation: contraction mode takes the general kernel
+    if (!fused) {
+        rc = launch_tiled_linear(in, out, W, H, B, in_stride, out_stride, 2 * s + 1, 2 * a + 1, kW * kH,
+                                 mode == IAK_LINEAR_AVERAGE, t, as_stream(stream));
+        if (rc != IAK_E_UNSUPPORTED) return rc;
+    }
     if (mode == IAK_LINEAR_CLAMP)
         hipLaunchKernelGGL((generic_float_kernel<G_LINEAR>), generic_grid(W, H, B), dim3(256), 0, as_stream(stream), in,
-                           out, W, H, in_stride, out_stride, kW, kH, t);
+                           out, W, H, in_stride, out_stride, kW, kH, t, fused);
     else
         hipLaunchKernelGGL((generic_float_kernel<G_AVERAGE>), generic_grid(W, H, B), dim3(256), 0, as_stream(stream), in,
-                           out, W, H, in_stride, out_stride, kW, kH, t);
+                           out, W, H, in_stride, out_stride, kW, kH, t, fused);
     IAK_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" {
 
 int iak_median(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
                const int *weights, int kW, int kH, void *stream) {

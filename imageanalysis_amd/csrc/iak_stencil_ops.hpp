@@ -121,12 +121,16 @@ struct FRow8 {
 // linear / average, float weights: `int sum; sum += uchar * float` of the reference
 // (imageAnalysis.cu:517-524) truncates after every tap; (int)x == truncf(x) for |x| < 2^31,
 // so the sum stays an integral float.
-template <bool AVERAGE>
+// FUSED: each tap as one fused multiply-add (contraction mode: nvcc's default build of the reference)
+template <bool AVERAGE, bool FUSED = false>
 struct Lin8Float {
     static const bool kBorderZero = true;
     static const bool kManyRegisters = true;
     typedef FRow8 Row;
     float k[9];
+    __device__ __forceinline__ static float tap(float sum, float px, float w) {
+        return truncf(FUSED ? __builtin_fmaf(px, w, sum) : sum + px * w);
+    }
     __device__ __forceinline__ void prepare(const Raw16 &q, int, int, int, int, FRow8 &f) const {
         f.f[0] = (float)(q.d[0] >> 24);
 #pragma unroll
@@ -143,15 +147,15 @@ struct Lin8Float {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             float sum = 0.0f;
-            sum = truncf(sum + u.f[j] * k[0]);
-            sum = truncf(sum + u.f[j + 1] * k[1]);
-            sum = truncf(sum + u.f[j + 2] * k[2]);
-            sum = truncf(sum + m.f[j] * k[3]);
-            sum = truncf(sum + m.f[j + 1] * k[4]);
-            sum = truncf(sum + m.f[j + 2] * k[5]);
-            sum = truncf(sum + d.f[j] * k[6]);
-            sum = truncf(sum + d.f[j + 1] * k[7]);
-            sum = truncf(sum + d.f[j + 2] * k[8]);
+            sum = tap(sum, u.f[j], k[0]);
+            sum = tap(sum, u.f[j + 1], k[1]);
+            sum = tap(sum, u.f[j + 2], k[2]);
+            sum = tap(sum, m.f[j], k[3]);
+            sum = tap(sum, m.f[j + 1], k[4]);
+            sum = tap(sum, m.f[j + 2], k[5]);
+            sum = tap(sum, d.f[j], k[6]);
+            sum = tap(sum, d.f[j + 1], k[7]);
+            sum = tap(sum, d.f[j + 2], k[8]);
             const int s = (int)sum;
             res[j] = AVERAGE ? s / 9 : imed3(s, 0, 255);
         }
@@ -678,8 +682,10 @@ inline LinPlan plan_linear3(const float *kernel) {
 
 
 // Runs `launch(op)` with the operator the plan selects (SWAR only for the clamping filter).
+// fused: contraction mode.  Only the general float operator differs: the others are chosen for weights whose
+// products are exact, where a fused multiply-add and a multiply followed by an add give the same bits.
 template <bool AVG, class L>
-inline int with_linear3_op(const float *kernel, L launch) {
+inline int with_linear3_op(const float *kernel, L launch, bool fused = false) {
     LinPlan p = plan_linear3(kernel);
     if (!AVG && p.kind != LIN_INT && p.kind != LIN_PK16 && plan_swar(kernel, p)) {
         Lin8Swar op;
@@ -700,6 +706,11 @@ inline int with_linear3_op(const float *kernel, L launch) {
         Lin8Fixed<AVG> op;
         for (int i = 0; i < 9; i++) op.k[i] = p.fk[i];
         op.q = p.q;
+        return launch(op);
+    }
+    if (fused) {
+        Lin8Float<AVG, true> op;
+        for (int i = 0; i < 9; i++) op.k[i] = kernel[i];
         return launch(op);
     }
     Lin8Float<AVG> op;

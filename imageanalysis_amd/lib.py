@@ -28,6 +28,8 @@ _vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 # name -> argtypes; every function returns int unless listed in _RESTYPE
 SIGNATURES = {
     "iak_version": [],
+    "iak_set_contraction": [_i],
+    "iak_get_contraction": [],
     "iak_error_string": [_i],
     "iak_malloc": [C.POINTER(_vp), C.c_size_t],
     "iak_free": [_vp],

@@ -39,6 +39,21 @@ int iak_version(void);
 /* Static string for a return code of this library (never NULL). */
 const char *iak_error_string(int code);
 
+/* Contraction mode (process-wide, default off).  The reference has two expressions of the form a * b + c in
+ * floating point whose product is not exact: the luminance (imageAnalysis.cu:22, double) and the filter
+ * accumulation `sum += pixel * weight` (:484, :521, float); cuRAND's uniform, x * 2^-32 + 2^-33, multiplies by a
+ * power of two and comes out the same either way.  Built by nvcc with its default
+ * -fmad=true each is one fused multiply-add with a single rounding; built with -fmad=false each operation
+ * rounds on its own.  Off reproduces the second build, on the first (fused the way LLVM's combiner fuses
+ * them: fma(.07, B, fma(.21, R, .72 * G)); fma(pixel, weight, sum)).  The grayscale conversion differs in about
+ * 0.17 % of all (R, G, B) triples, always by one grey level; filters differ only for weights whose products are
+ * not exact in float (none of the reference's configurations).  Nothing the reference ships pins either build.
+ * Read by iak_gray*, iak_linear at every call and by iak_pipeline_create once (a
+ * pipeline keeps the setting it was created under).  In contraction mode linear / average filters larger than
+ * 3x3 take the one-pixel-per-lane kernel. */
+int iak_set_contraction(int enabled);
+int iak_get_contraction(void);
+
 /* ---- memory / stream helpers, so a host never has to name hip* itself ----------
  * Replace cudaMalloc/cudaFree/cudaMemcpy in imageAnalysis.cu:866-907. These DO
  * allocate / free / block as their names say. */

@@ -15,6 +15,17 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Contraction mode.  The reference's two expressions of the form a * b + c whose product is not exact -- the
+ * luminance (imageAnalysis.cu:22) and the filter accumulation (:521) -- are compiled by nvcc, which by
+ * default (-fmad=true) contracts such an expression into one fused multiply-add with a single rounding.  Off
+ * (the default here): every operation rounds on its own.  On: the two sites are fused the way LLVM's
+ * combiner fuses them (the left product of a sum of two products first; then a product into the sum it is
+ * added to).  Neither setting is pinned by anything the reference ships: the switch exists so that the two
+ * possible builds can be compared. */
+static int g_contract = 0;
+void iao_set_contraction(int on) { g_contract = on != 0; }
+int iao_get_contraction(void) { return g_contract; }
+
 /* float -> unsigned char: C leaves out-of-range values undefined; the
  * reference relies on it (imageAnalysis.cu:552,844).  Fixed here as
  * truncate toward zero to int, then modulo 256; NaN -> 0. */
@@ -38,10 +49,15 @@ int iao_gray(const uint8_t *rgb, uint8_t *gray, int W, int H, int method) {
     if (method == 0) {
         /* imageAnalysis.cu:22 -- literals are double, so the sum is double. */
         for (long t = 0; t < N; t++) {
-            double r = .21 * rgb[t];
-            double g = .72 * rgb[t + N];
-            double b = .07 * rgb[t + 2 * N];
-            double y = (r + g) + b;
+            double y;
+            if (g_contract) {
+                y = fma(.07, (double)rgb[t + 2 * N], fma(.21, (double)rgb[t], .72 * rgb[t + N]));
+            } else {
+                double r = .21 * rgb[t];
+                double g = .72 * rgb[t + N];
+                double b = .07 * rgb[t + 2 * N];
+                y = (r + g) + b;
+            }
             gray[t] = (uint8_t)y; /* 0 <= y < 256 always */
         }
         return 0;
@@ -282,7 +298,8 @@ void iao_xorwow_stream(unsigned long long seed, unsigned int subsequence, int n,
 }
 
 float iao_uniform(uint32_t x) {
-    /* curand_uniform: x * 2^-32 + 2^-33 in float, two roundings (no fma). */
+    /* curand_uniform: x * 2^-32 + 2^-33 in float.  The factor is 2^-32 exactly, so the product is exact and a
+     * fused multiply-add (nvcc's default) gives the same bits: contraction mode does not touch it. */
     float f = (float)x * 2.3283064e-10f;
     return f + (2.3283064e-10f / 2.0f);
 }
@@ -388,8 +405,13 @@ static inline int accumulate(const uint8_t *in, long N, int W, int row, int col,
     int k = 0;
     for (int i = row - a; i <= row + a; i++)
         for (int j = col - s; j <= col + s; j++) {
-            float prod = (float)tap(in, N, (long)i * W + j) * kernel[k];
-            float acc = (float)sum + prod;
+            float acc;
+            if (g_contract) {
+                acc = fmaf((float)tap(in, N, (long)i * W + j), kernel[k], (float)sum);
+            } else {
+                float prod = (float)tap(in, N, (long)i * W + j) * kernel[k];
+                acc = (float)sum + prod;
+            }
             sum = (int)acc;
             k++;
         }

@@ -36,6 +36,13 @@
 extern "C" {
 #endif
 
+/* ---- contraction mode ---------------------------------------------------- */
+/* on != 0: the luminance (imageAnalysis.cu:22) and the filter accumulation (:521) are evaluated
+ * with fused multiply-adds, as nvcc's default -fmad=true would compile them; 0 (default): every operation
+ * rounds on its own.  Process-wide; not for use while other threads run oracle functions. */
+void iao_set_contraction(int on);
+int iao_get_contraction(void);
+
 /* ---- colour ------------------------------------------------------------ */
 /* imageAnalysis.cu:17-37,43-70.  rgb is planar R|G|B, 3*W*H bytes.
  * method 0: (uchar)((.21*R)+(.72*G)+(.07*B)) in double; 1: (R+G+B)/3.

@@ -44,6 +44,8 @@ def lib():
     if not os.path.exists(_SO):
         build()
     L = C.CDLL(_SO)
+    L.iao_set_contraction.argtypes = [C.c_int]
+    L.iao_set_contraction.restype = None
     L.iao_gray.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int]
     L.iao_gray.restype = C.c_int
     L.iao_hist.argtypes = [u8p, C.c_long, i32p]
@@ -354,3 +356,17 @@ def pipeline(rgb, ops, x0=None, x1=None, threads=1):
                        x1.ctypes.data if x1 is not None else None, hs, threads)
     del keep
     return out, hs
+
+
+class contraction:
+    """with contraction(): ... -- the oracle in contraction mode (the luminance and the filter accumulation as
+    fused multiply-adds, as nvcc's default build of the reference evaluates them); back to separate roundings
+    afterwards."""
+
+    def __enter__(self):
+        lib().iao_set_contraction(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().iao_set_contraction(0)
+        return False

@@ -30,11 +30,15 @@ pmc_of() {  # <dir> <counters> -- <bench args...>
     echo "pmc $d done"
 }
 stats_of PA --no-other-workloads
+# config 3's per-GPU share (1250 images): the intermediates (545 MB each) no longer fit the 256 MiB Infinity Cache
+stats_of PA_B1250 --no-other-workloads --batch 1250 --no-cpu-baseline
 stats_of PB --workload P-B --steps 20 --no-cpu-baseline
 stats_of PC --workload P-C --no-cpu-baseline
 pmc_of /tmp/pmc_fetch FETCH_SIZE --
 pmc_of /tmp/pmc_write WRITE_SIZE --
 pmc_of /tmp/pmc_sq_PA $SQ --
+pmc_of /tmp/pmc_fetch_B1250 FETCH_SIZE -- --batch 1250
+pmc_of /tmp/pmc_write_B1250 WRITE_SIZE -- --batch 1250
 pmc_of /tmp/pmc_sq_PAcfg $SQ -- --linear-kernel config
 pmc_of /tmp/pmc_sq_PB $SQ -- --workload P-B
 pmc_of /tmp/pmc_sq_PC $SQ -- --workload P-C
@@ -59,7 +63,10 @@ done
 # ... and the same entry points timed plainly (no counters): the figures to quote
 timeout -k 10 120 python3 tools/kbench.py --only gray_hist,hist,gray --reps 20 > "$out/kbench_hist.txt" 2>&1 || true
 python3 tools/make_traffic.py /tmp/pmc_fetch /tmp/pmc_write 500 "$out/traffic.json" > /dev/null
+python3 tools/make_traffic.py /tmp/pmc_fetch_B1250 /tmp/pmc_write_B1250 1250 "$out/traffic_B1250.json" > /dev/null
 # the plain run, with the measured traffic and issue times in place, is the line to compare with the profiles
-mkdir -p profiles && cp "$out/traffic.json" profiles/traffic.json && cp "$out/valu.json" profiles/valu.json
+mkdir -p profiles && cp "$out/traffic.json" profiles/traffic.json && cp "$out/traffic_B1250.json" profiles/traffic_B1250.json && cp "$out/valu.json" profiles/valu.json
 timeout -k 10 300 python3 bench.py > "$out/bench.json"
+timeout -k 10 300 python3 bench.py --batch 1250 --no-cpu-baseline > "$out/bench_B1250.json"
+timeout -k 10 300 python3 bench.py --batch 2000 --no-cpu-baseline > "$out/bench_B2000.json"
 cat "$out/bench.json"
