@@ -514,7 +514,9 @@ class Measurement:
                 if v and B == valu_batch:  # the counter passes run the default batch
                     # share of the launch during which the vector pipes were issuing, from the SQ counter pass
                     issue_s = v["valu_busy_simd_cycles_per_launch"] / N_SIMDS / CLOCK_HZ
-                    g["valu_issue_frac"] = round(issue_s / (mm * 1e-3), 4)
+                    # (the counter tallies some instructions at more than one issue slot, so a kernel that does nothing
+                    # but vector instructions can come out a little above 1: clipped)
+                    g["valu_issue_frac"] = min(1.0, round(issue_s / (mm * 1e-3), 4))
                     used_valu = True
                     if g["valu_issue_frac"] > g["hbm_frac"]:
                         g["bound"] = "valu"
