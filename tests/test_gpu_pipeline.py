@@ -148,6 +148,29 @@ def test_pipeline_matches_oracle(Pipeline, name, fused, W, H, kind):
     p.close()
 
 
+@pytest.mark.parametrize("name", ["P-A", "input.json", "sp+median", "big-stencils"])
+@pytest.mark.parametrize("W,H,kind", [(768, 40, "C"), (64, 48, "U"), (1024, 43, "U")])
+def test_pipeline_with_the_specialised_kernels_switched_off(Pipeline, monkeypatch, name, W, H, kind):
+    """IAK_NO_LGS (read when a pipeline is planned) sends look-up / Gaussian / salt-pepper runs to the generic fused
+    kernel, IAK_NO_BITSLICE_MEDIAN (read per call) sends small all-ones medians to the column-histogram kernel:
+    the same images either way."""
+    if name not in CHAINS:
+        pytest.skip("no such chain here")
+    ops = CHAINS[name]
+    rgb = synth.rgb_batch(kind, W, H, 2)
+    x0, x1 = O.xorwow_planes(W * H)
+    want, _ = O.pipeline(rgb, ops, x0, x1)
+    dev = torch.from_numpy(rgb).cuda()
+    p = Pipeline(W, H, 2, ops, fused=True)
+    assert np.array_equal(p.run(dev).cpu().numpy(), want)
+    p.close()
+    monkeypatch.setenv("IAK_NO_LGS", "1")
+    monkeypatch.setenv("IAK_NO_BITSLICE_MEDIAN", "1")
+    p = Pipeline(W, H, 2, ops, fused=True)
+    assert np.array_equal(p.run(dev).cpu().numpy(), want)
+    p.close()
+
+
 def test_pipeline_smaller_batch_than_planned(Pipeline):
     W, H = 64, 48
     rgb = synth.rgb_batch("C", W, H, 5)
