@@ -325,11 +325,15 @@ def test_median_sliding_histogram(ops, kW, kH, W, H, kind):
     each(lambda x: ops.medianFilter(x, w, kW, kH), lambda x: O.median(x, w, kW, kH), imgs)
 
 
-@pytest.mark.parametrize("W,H", [(8, 11), (16, 3), (24, 2), (768, 40), (64, 64), (8, 1), (40, 5)])
+@pytest.mark.parametrize("kW,kH", [(5, 5), (7, 7), (5, 7), (7, 5), (3, 5), (5, 3), (3, 7), (7, 3)])
+@pytest.mark.parametrize("W,H", [(8, 11), (16, 3), (24, 2), (768, 40), (64, 64), (8, 1), (40, 5), (4, 1), (4, 9), (36, 33),
+                                 (260, 35), (516, 70), (252, 31), (1028, 3)])
 @pytest.mark.parametrize("kind", ["U", "C", "K", "binary", "ramp"])
-def test_median5_network(ops, W, H, kind):
-    """The 5x5 median's comparator network (widths that are multiples of 8): one chunk wide, fewer
-    rows than the window, pixel values at both ends of the range, ties everywhere."""
+def test_median_bit_sliced(ops, kW, kH, W, H, kind):
+    """All-ones medians of up to 49 taps on widths that are multiples of 4 (the bit-plane kernel's cases): every
+    window shape it is built for; images of one word, one row, fewer rows or columns than the window, one column of
+    tiles plus a few pixels (260, 516, 1028), one pixel short of a tile (252 x 31); pixel values at both ends of
+    the range and ties everywhere; two images, so the second starts where the first one's halo loads reach."""
     rs = np.random.default_rng(W * 100 + H)
     if kind == "binary":
         imgs = (rs.integers(0, 2, (2, H, W)) * 255).astype(np.uint8)
@@ -337,8 +341,32 @@ def test_median5_network(ops, W, H, kind):
         imgs = ((np.arange(2 * H * W).reshape(2, H, W) * 7) % 256).astype(np.uint8)
     else:
         imgs = batch(kind, W, H, 2)
-    w = [1] * 25
-    each(lambda x: ops.medianFilter(x, w, 5, 5), lambda x: O.median(x, w, 5, 5), imgs)
+    w = [1] * (kW * kH)
+    each(lambda x: ops.medianFilter(x, w, kW, kH), lambda x: O.median(x, w, kW, kH), imgs)
+
+
+def test_median_bit_sliced_in_a_strided_batch(ops):
+    """Images inside a larger allocation: rows of the next image's slot must not leak into the last rows' windows,
+    and an image stride that is no multiple of the tile keeps the 4-byte alignment the kernel asks for."""
+    W, H, B = 132, 37, 3
+    imgs = batch("U", W, H, B)
+    stride = W * H + 52
+    buf = torch.full((B * stride + 64,), 255, dtype=torch.uint8, device="cuda")
+    view = buf[: B * stride].view(B, stride)
+    view[:, : W * H] = torch.from_numpy(imgs.reshape(B, -1)).cuda()
+    out = torch.zeros_like(buf)
+    from imageanalysis_amd import lib as L
+    h = L.load()
+    import ctypes as C
+    for kW, kH in ((7, 7), (5, 3)):
+        w = (C.c_int * (kW * kH))(*[1] * (kW * kH))
+        rc = h.iak_median(buf.data_ptr(), out.data_ptr(), W, H, B, stride, stride, w, kW, kH, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        got = out[: B * stride].view(B, stride)[:, : W * H].cpu().numpy().reshape(B, H, W)
+        for b in range(B):
+            assert np.array_equal(got[b], O.median(imgs[b], [1] * (kW * kH), kW, kH)), (kW, kH, b)
+        assert int(out[: B * stride].view(B, stride)[:, W * H:].max()) == 0  # nothing written between the images
 
 
 @pytest.mark.parametrize("kW,kH", [(51, 5), (255, 1), (1, 255), (27, 9)])
