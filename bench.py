@@ -144,7 +144,7 @@ KERNEL_OF_GROUP = {
 KERNEL_OF_GROUP_BY_WORKLOAD = {
     "P-A/config": {"equalize+gauss+salt_pepper+linear": "iak::lgs_stencil8_flat_kernel<iak::Lin8Pk16<false> >",
                    "linear": "iak::stencil8_kernel<iak::Lin8Pk16<false>, 8, false, false>"},
-    "P-B": {"linear": "iak::box_special_kernel<false, 11>", "median": "iak::bitslice_median_kernel<7, 7>"},
+    "P-B": {"linear": "iak::bitslice_box_kernel<11, 11>", "median": "iak::bitslice_median_kernel<7, 7>"},
     "P-C": {"otsu": "iak::chain_apply_kernel<false>", "otsu+sobel": "iak::binary_table_stencil_kernel",
             "dilate+erode+hist": "iak::morph_chain_kernel<2, 2, false>", "features": "iak::perimeter_bits_kernel"},
 }

@@ -391,6 +391,7 @@ __global__ __launch_bounds__(256) void box_special_kernel(const uint8_t *__restr
 
 }  // namespace iak
 #include "iak_box_rows.hpp"
+#include "iak_box_bits.hpp"
 namespace iak {
 
 // kW, kH: the odd window actually visited (at most 25 x 25); w its one weight; divisor: for the
@@ -417,6 +418,10 @@ static int launch_box_sum(const uint8_t *in, uint8_t *out, int W, int H, int B, 
     // rows that start at multiples of 4 bytes: the tile is staged a dword at a time
     const bool wide = W % 4 == 0 && reinterpret_cast<uintptr_t>(in) % 4 == 0 && in_stride % 4 == 0;
     if (memo.kind == BOX_SPECIAL) {
+        if (!avg && !getenv("IAK_NO_BITSLICE_BOX")) {  // square windows, linear filter: 32 pixels per register
+            const int rc = launch_bitslice_box(in, out, W, H, B, in_stride, out_stride, kW, kH, w, memo.sp, s);
+            if (rc != IAK_E_UNSUPPORTED) return rc;
+        }
         const dim3 grid((unsigned)(tiles_x * ((H + BXS_TY - 1) / BXS_TY)), B);
 #define BXS_CASE(K)                                                                                                       \
     case K:                                                                                                               \

@@ -14,8 +14,8 @@
 //
 // The image reaches that form as eight bit planes in LDS: a workgroup loads the byte tile it needs (on the flat
 // view of the image, so a window column past a row's end is the next row's pixel and offsets outside the image
-// read 0, as in the reference), each lane transposes 32 pixels to eight plane words (an 8x8 bit-matrix transpose
-// on register pairs plus byte permutes), and the tap (dx, dy) of a lane's 32 pixels is a funnel shift of plane
+// read 0, as in the reference), each lane transposes 32 pixels to eight plane words (byte permutes and bit
+// exchanges between registers), and the tap (dx, dy) of a lane's 32 pixels is a funnel shift of plane
 // words of row y + dy.  The median's eight bit words go back to bytes by the same transpose.
 #pragma once
 #include "iak_common.hpp"
@@ -26,51 +26,70 @@ namespace iak {
 #define MB_TH 32   // output rows per workgroup
 #define MB_WORDS (MB_TW / 32 + 2)  // plane words per tile row: the tile's columns and 32 on either side
 
-// 8 x 8 bit-matrix transpose on a register pair: in, byte j of (lo, hi) is pixel j; out, byte b holds bit b of
-// the eight pixels (pixel j at bit j).  Its own inverse.
-__device__ __forceinline__ void mb_transpose8(uint32_t &lo, uint32_t &hi) {
-    uint32_t t;
-    t = ((lo >> 7) ^ lo) & 0x00aa00aau; lo ^= t ^ (t << 7);
-    t = ((hi >> 7) ^ hi) & 0x00aa00aau; hi ^= t ^ (t << 7);
-    t = ((lo >> 14) ^ lo) & 0x0000ccccu; lo ^= t ^ (t << 14);
-    t = ((hi >> 14) ^ hi) & 0x0000ccccu; hi ^= t ^ (t << 14);
-    t = ((lo >> 4) ^ hi) & 0x0f0f0f0fu;
-    hi ^= t;
-    lo ^= t << 4;
-}
-// 4 x 4 byte transpose: out[i] byte j = in[j] byte i
-__device__ __forceinline__ void mb_transpose4x4(const uint32_t in[4], uint32_t out[4]) {
-    const uint32_t a = __builtin_amdgcn_perm(in[1], in[0], 0x05010400u);  // in0.b0 in1.b0 in0.b1 in1.b1
-    const uint32_t b = __builtin_amdgcn_perm(in[1], in[0], 0x07030602u);  // in0.b2 in1.b2 in0.b3 in1.b3
-    const uint32_t c = __builtin_amdgcn_perm(in[3], in[2], 0x05010400u);
-    const uint32_t d = __builtin_amdgcn_perm(in[3], in[2], 0x07030602u);
-    out[0] = __builtin_amdgcn_perm(c, a, 0x05040100u);
-    out[1] = __builtin_amdgcn_perm(c, a, 0x07060302u);
-    out[2] = __builtin_amdgcn_perm(d, b, 0x05040100u);
-    out[3] = __builtin_amdgcn_perm(d, b, 0x07060302u);
+// Three-input logic as one instruction: TT is the function's truth table, i.e. the expression evaluated on
+// a = 0xf0, b = 0xcc, c = 0xaa.
+template <int TT>
+__device__ __forceinline__ uint32_t mb_op3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
 }
 // 32 pixels (bytes of px[0..7], pixel 4 i + j = byte j of px[i]) <-> eight plane words (plane[b] bit p = bit b of
-// pixel p).  The two directions are the same two steps in opposite order.
+// pixel p).  An element sits at (register i2 i1 i0, bit position j1 j0 b2 b1 b0) and belongs at (register b2 b1 b0,
+// position i2 i1 i0 j1 j0): five exchanges of a register-index bit with a position bit, each on four register
+// pairs -- two of whole bytes (one byte permute per register), three of nibbles / bit pairs / bits (a shift and a
+// bit select per register) -- leave plane b in register b1 b0 b2.  Every exchange is its own inverse, so the way
+// back is the same steps in the opposite order.
+template <int SH>
+__device__ __forceinline__ void mb_exchange(uint32_t &lo, uint32_t &hi) {
+    // position bit log2(SH) of `lo` <-> the register bit that tells lo from hi
+    constexpr uint32_t M = SH == 4 ? 0x0f0f0f0fu : (SH == 2 ? 0x33333333u : 0x55555555u);
+    const uint32_t l = mb_op3<0xca>(M << SH, hi << SH, lo);  // lo keeps its M bits, takes hi's M bits above them
+    hi = mb_op3<0xca>(M, lo >> SH, hi);
+    lo = l;
+}
 __device__ __forceinline__ void mb_bytes_to_planes(const uint32_t px[8], uint32_t plane[8]) {
-    uint32_t lo[4], hi[4];
+    uint32_t r[8], t[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {  // pixels 8k .. 8k+7: byte b of (lo, hi) = bit b of those eight
-        lo[k] = px[2 * k];
-        hi[k] = px[2 * k + 1];
-        mb_transpose8(lo[k], hi[k]);
+    for (int i = 0; i < 4; i++) {  // register bit 2 <-> byte-index bit 1
+        t[i] = __builtin_amdgcn_perm(px[i + 4], px[i], 0x05040100u);
+        t[i + 4] = __builtin_amdgcn_perm(px[i + 4], px[i], 0x07060302u);
     }
-    mb_transpose4x4(lo, plane);      // plane b = byte b of lo[0..3]: pixels 0-7, 8-15, 16-23, 24-31
-    mb_transpose4x4(hi, plane + 4);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {  // register bit 1 <-> byte-index bit 0
+        if (i & 2) continue;
+        r[i] = __builtin_amdgcn_perm(t[i + 2], t[i], 0x06020400u);
+        r[i + 2] = __builtin_amdgcn_perm(t[i + 2], t[i], 0x07030501u);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) mb_exchange<4>(r[i], r[i + 1]);  // register bit 0 <-> pixel bit 2
+#pragma unroll
+    for (int i = 0; i < 4; i++) mb_exchange<2>(r[i], r[i + 4]);     // register bit 2 <-> pixel bit 1
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (!(i & 2)) mb_exchange<1>(r[i], r[i + 2]);              // register bit 1 <-> pixel bit 0
+#pragma unroll
+    for (int b = 0; b < 8; b++) plane[b] = r[((b >> 1) & 1) * 4 + (b & 1) * 2 + (b >> 2)];
 }
 __device__ __forceinline__ void mb_planes_to_bytes(const uint32_t plane[8], uint32_t px[8]) {
-    uint32_t lo[4], hi[4];
-    mb_transpose4x4(plane, lo);
-    mb_transpose4x4(plane + 4, hi);
+    uint32_t r[8], t[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        mb_transpose8(lo[k], hi[k]);
-        px[2 * k] = lo[k];
-        px[2 * k + 1] = hi[k];
+    for (int b = 0; b < 8; b++) r[((b >> 1) & 1) * 4 + (b & 1) * 2 + (b >> 2)] = plane[b];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (!(i & 2)) mb_exchange<1>(r[i], r[i + 2]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) mb_exchange<2>(r[i], r[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) mb_exchange<4>(r[i], r[i + 1]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i & 2) continue;
+        t[i] = __builtin_amdgcn_perm(r[i + 2], r[i], 0x06020400u);
+        t[i + 2] = __builtin_amdgcn_perm(r[i + 2], r[i], 0x07030501u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        px[i] = __builtin_amdgcn_perm(t[i + 4], t[i], 0x05040100u);
+        px[i + 4] = __builtin_amdgcn_perm(t[i + 4], t[i], 0x07060302u);
     }
 }
 
@@ -82,12 +101,6 @@ struct MbNum {
     static constexpr int W = mb_width(MAXV);
     uint32_t b[W];
 };
-// Three-input logic as one instruction: TT is the function's truth table, i.e. the expression evaluated on
-// a = 0xf0, b = 0xcc, c = 0xaa.
-template <int TT>
-__device__ __forceinline__ uint32_t mb_op3(uint32_t a, uint32_t b, uint32_t c) {
-    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
-}
 __device__ __forceinline__ void mb_full_add(uint32_t x, uint32_t y, uint32_t z, uint32_t &sum, uint32_t &carry) {
     sum = mb_op3<0x96>(x, y, z);    // x ^ y ^ z
     carry = mb_op3<0xe8>(x, y, z);  // majority

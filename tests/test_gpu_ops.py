@@ -281,8 +281,9 @@ def test_box_filters(ops, w, kW, kH, W, H, kind):
 
 
 @pytest.mark.parametrize("kW,kH,w", [(11, 11, 1.0 / 121), (7, 7, 1.0 / 49), (13, 13, 1.0 / 169), (11, 5, 1.0 / 55),
-                                       (3, 15, 1.0 / 45), (25, 9, 1.0 / 121), (11, 11, 1.0 / 242), (11, 11, 3.0 / 242)])
-@pytest.mark.parametrize("W,H", [(200, 70), (64, 64), (131, 45), (9, 40)])
+                                       (3, 15, 1.0 / 45), (25, 9, 1.0 / 121), (11, 11, 1.0 / 242), (11, 11, 3.0 / 242),
+                                       (9, 9, 1.0 / 81), (15, 15, 1.0 / 225), (5, 5, 1.0 / 100), (7, 7, 3.0 / 242)])
+@pytest.mark.parametrize("W,H", [(200, 70), (64, 64), (131, 45), (9, 40), (2080, 40), (4100, 35), (256, 100), (32, 9), (4, 30)])
 def test_box_filters_whose_taps_depend_on_the_running_sum(ops, kW, kH, w, W, H):
     """Weights like fl(1/121): 121 * w lies one float step below 1, so that tap adds 0 to an empty
     running sum and 1 to any other (imageAnalysis.cu:517-524 truncates after every tap) -- the

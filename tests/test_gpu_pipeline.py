@@ -152,10 +152,9 @@ def test_pipeline_matches_oracle(Pipeline, name, fused, W, H, kind):
 @pytest.mark.parametrize("W,H,kind", [(768, 40, "C"), (64, 48, "U"), (1024, 43, "U")])
 def test_pipeline_with_the_specialised_kernels_switched_off(Pipeline, monkeypatch, name, W, H, kind):
     """IAK_NO_LGS (read when a pipeline is planned) sends look-up / Gaussian / salt-pepper runs to the generic fused
-    kernel, IAK_NO_BITSLICE_MEDIAN (read per call) sends small all-ones medians to the column-histogram kernel:
-    the same images either way."""
-    if name not in CHAINS:
-        pytest.skip("no such chain here")
+    kernel, IAK_NO_BITSLICE_MEDIAN (read per call) sends small all-ones medians to the column-histogram kernel,
+    IAK_NO_BITSLICE_BOX (read per call) sends box filters with sum-dependent taps to the integer-sum kernel: the same
+    images either way."""
     ops = CHAINS[name]
     rgb = synth.rgb_batch(kind, W, H, 2)
     x0, x1 = O.xorwow_planes(W * H)
@@ -166,6 +165,7 @@ def test_pipeline_with_the_specialised_kernels_switched_off(Pipeline, monkeypatc
     p.close()
     monkeypatch.setenv("IAK_NO_LGS", "1")
     monkeypatch.setenv("IAK_NO_BITSLICE_MEDIAN", "1")
+    monkeypatch.setenv("IAK_NO_BITSLICE_BOX", "1")
     p = Pipeline(W, H, 2, ops, fused=True)
     assert np.array_equal(p.run(dev).cpu().numpy(), want)
     p.close()
