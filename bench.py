@@ -146,7 +146,8 @@ KERNEL_OF_GROUP_BY_WORKLOAD = {
                    "linear": "iak::stencil8_kernel<iak::Lin8Pk16<false>, 8, false, false>"},
     "P-B": {"linear": "iak::bitslice_box_kernel<11, 11>", "median": "iak::bitslice_median_kernel<7, 7>"},
     "P-C": {"otsu": "iak::chain_apply_kernel<false>", "otsu+sobel": "iak::binary_table_stencil_kernel",
-            "dilate+erode+hist": "iak::morph_chain_kernel<2, 2, false>", "features": "iak::perimeter_bits_kernel"},
+            "dilate+erode+hist": "iak::morph_bits_kernel<2, false, true>",
+            "otsu+sobel+dilate+erode+hist": "iak::morph_bits_kernel<3, true, true>", "features": "iak::perimeter_bits_kernel"},
 }
 P_B = [
     {"type": OP_LINEAR, "kW": 11, "kH": 11, "fkernel": [1.0 / 121] * 121},

@@ -19,9 +19,9 @@
 //    starting at t + 1 (right whenever the window holds a contributing tap at all), and "holds a contributing tap"
 //    = rows since the last row with C < KH.  No branch depends on pixel data.
 //
-// A wave covers up to 62 words of a row band (its first and last lane only supply their neighbours' edge
-// pixels); what is left of a row after the 62-word segments is packed several strips to a wave.
+// Which lane has which word of which strip: iak_bitrows.hpp.
 #pragma once
+#include "iak_bitrows.hpp"
 #include "iak_median_bits.hpp"  // included from iak_box.hpp, behind BoxSpecial
 
 namespace iak {
@@ -29,15 +29,7 @@ namespace iak {
 struct BsbDesc {
     uint32_t thr[3];      // pixel >= thr[k]  <=>  floor(pixel * w) > k   (256: no pixel)
     uint32_t special[4];  // the special pixel values (256: unused)
-    int rows;             // output rows per strip
-    int strips;           // strips per image
-    int words;            // 32-pixel words per image row (the last one may reach into the next row)
-    int nfull;            // 62-word segments per row
-    int rem_lanes;        // lanes of the row's remaining segment (its words + 2), 0 if there is none
-    int pack;             // remaining segments (of different strips) per wave
-    int waves_full;       // strips * nfull
-    int waves;            // waves per image
-    int images;
+    BitRows g;
 };
 
 // the count of up to 15 one-bit inputs
@@ -125,40 +117,21 @@ __device__ __forceinline__ void bsb_load(__amdgpu_buffer_rsrc_t rsrc, int f, int
     }
 }
 
-// the word of the lane below / above in the wave (whatever for the wave's first / last lane)
-__device__ __forceinline__ uint32_t bsb_from_left(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, true); }   // wave_shr:1
-__device__ __forceinline__ uint32_t bsb_from_right(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, true); }  // wave_shl:1
-
 template <int KW, int KH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void bitslice_box_kernel(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int W, int H, long long in_stride, long long out_stride, BsbDesc d) {
     constexpr int s = (KW - 1) / 2, a = (KH - 1) / 2;
     constexpr int FSW = mb_width(4 * KW), CW = mb_width(KW), SUMW = mb_width(4 * KW * KH), BEFW = mb_width(KW * KH);
     static_assert(KW <= 15 && KH <= 15 && SUMW <= 10 && BEFW <= SUMW, "bit-sliced box: window");
-    const int gwave = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int image = gwave / d.waves, wave = gwave - image * d.waves;
-    if (image >= d.images) return;
-    // which strip and which word of the row this lane has
-    int strip, wj;
+    int image, strip, wj;
     bool stores;
-    if (wave < d.waves_full) {
-        strip = wave / d.nfull;
-        const int seg = wave - strip * d.nfull;
-        wj = seg * 62 + lane - 1;
-        stores = lane >= 1 && lane <= 62;
-    } else {
-        const int sub = lane / d.rem_lanes, li = lane - sub * d.rem_lanes;
-        strip = (wave - d.waves_full) * d.pack + sub;
-        wj = d.nfull * 62 + li - 1;
-        stores = sub < d.pack && strip < d.strips && li >= 1 && li <= d.rem_lanes - 2;
-    }
-    stores = stores && wj < d.words;
+    if (!d.g.locate(blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), threadIdx.x & 63, &image, &strip, &wj, &stores)) return;
     const int N = W * H;  // the launcher keeps W * (H + 64) below 2^31
     const uint8_t *src = in + (long long)image * in_stride;
     uint8_t *dst = out + (long long)image * out_stride;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
     const int col0 = 32 * wj;
-    const int ys = min(strip, d.strips) * d.rows;  // lanes without a strip read below the image: zeros
+    const int ys = min(strip, d.g.strips) * d.g.rows;  // lanes without a strip read below the image: zeros
     // columns of the image's two edges are zero in the output (imageAnalysis.cu:509)
     uint32_t keep = 0xffffffffu;
     if (col0 < s) keep &= col0 + 31 < s ? 0u : 0xffffffffu << (s - col0);
@@ -177,8 +150,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 #pragma unroll
     for (int i = 0; i < 4; i++) dist[i] = 0xffffffffu;
 
-    const int steps = d.rows + KH - 1;
-    int r = ys + d.rows - 1 + a;  // the input row of the step: the bottom row of the strip's last window first
+    const int steps = d.g.rows + KH - 1;
+    int r = ys + d.g.rows - 1 + a;  // the input row of the step: the bottom row of the strip's last window first
     uint32_t px[8];
     bsb_load(rsrc, r * W + col0, N, px);
 
@@ -196,9 +169,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         f0[1] = mb_op3<0x96>(ge1, ge2, ge3);
         f1[1] = ge2;
         sp[1] = bsb_eq(pl, v0) | bsb_eq(pl, v1) | bsb_eq(pl, v2) | bsb_eq(pl, v3);
-        f0[0] = bsb_from_left(f0[1]); f0[2] = bsb_from_right(f0[1]);
-        f1[0] = bsb_from_left(f1[1]); f1[2] = bsb_from_right(f1[1]);
-        sp[0] = bsb_from_left(sp[1]); sp[2] = bsb_from_right(sp[1]);
+        f0[0] = word_from_left(f0[1]); f0[2] = word_from_right(f0[1]);
+        f1[0] = word_from_left(f1[1]); f1[2] = word_from_right(f1[1]);
+        sp[0] = word_from_left(sp[1]); sp[2] = word_from_right(sp[1]);
         // the row's window quantities
         uint32_t zf0[KW], zf1[KW], zs[KW], zg[KW];
         uint32_t seen = 0u;  // a contributing tap in front of this one
@@ -263,8 +236,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         if (stores && y < H) {
             uint8_t *q = dst + (long long)y * W + col0;
             if (col0 + 32 <= W) {
-                st16(q, u32x4{ob[0], ob[1], ob[2], ob[3]});
-                st16(q + 16, u32x4{ob[4], ob[5], ob[6], ob[7]});
+                st16<IAK_NT_STENCIL_ST>(q, u32x4{ob[0], ob[1], ob[2], ob[3]});
+                st16<IAK_NT_STENCIL_ST>(q + 16, u32x4{ob[4], ob[5], ob[6], ob[7]});
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; i++)
@@ -299,34 +272,21 @@ static int launch_bitslice_box(const uint8_t *in, uint8_t *out, int W, int H, in
         for (int k = 0; k < f; k++) d.thr[k] = (uint32_t)px;
     }
     for (int k = 0; k < BOX_MAX_SPECIAL; k++) d.special[k] = sp.value[k];
-    d.words = (W + 31) / 32;
-    d.nfull = d.words / 62;
-    const int rem = d.words - 62 * d.nfull;
-    d.rem_lanes = rem ? rem + 2 : 0;
-    d.pack = rem ? 64 / d.rem_lanes : 0;
     // Rows per strip.  The kernel is bound by its vector instructions, a workgroup is four waves, one per SIMD of
     // its CU, and a CU holds three workgroups of this size: the time is about (workgroups of the busiest CU) x
     // (steps of a strip), rows + KH - 1 with two more for the start.  Up to one round of resident workgroups the
     // busiest CU has a whole number of them; beyond that the dispatcher evens the CUs out.
-    auto waves_for = [&](int rows_) {
-        const int strips = (H + rows_ - 1) / rows_;
-        return strips * d.nfull + (rem ? (strips + d.pack - 1) / d.pack : 0);
-    };
     int rows = 32;
     double best = 1e30;
     for (int r_ = 8; r_ <= 48; r_++) {
-        const long long wgs = ((long long)waves_for(r_) * B + 3) / 4;
+        const long long wgs = ((long long)BitRows::waves_per_image(W, H, r_) * B + 3) / 4;
         const double per_cu = wgs <= 3 * 256 ? (double)((wgs + 255) / 256) : (double)wgs / 256.0;
         const double cost = per_cu * (r_ + kH + 1);
         if (cost < best) { best = cost; rows = r_; }
     }
     if (const char *e = getenv("IAK_BSB_ROWS")) rows = atoi(e) > 0 && atoi(e) <= 48 ? atoi(e) : rows;  // for measurements
-    d.rows = rows;
-    d.strips = (H + rows - 1) / rows;
-    d.waves_full = d.strips * d.nfull;
-    d.waves = waves_for(rows);
-    d.images = B;
-    const dim3 grid((unsigned)(((long long)d.waves * B + 3) / 4));
+    d.g = BitRows::make(W, H, B, rows);
+    const dim3 grid(d.g.grid_blocks());
 #define BSB_CASE(K)                                                                                                       \
     if (kW == K) {                                                                                                        \
         hipLaunchKernelGGL((bitslice_box_kernel<K, K>), grid, dim3(256), 0, s, in, out, W, H, in_stride, out_stride, d);   \

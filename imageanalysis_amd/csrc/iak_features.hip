@@ -335,8 +335,7 @@ __global__ void glibc_rand_centroids_kernel(uint32_t *__restrict__ state, int im
 // differences over the first A-1 attributes in order, then sqrt; the last attribute is the
 // class.  The reference picks its k candidates with a shared-memory tournament that races and
 // reads one distance per thread slot (:103-140); here the k nearest are taken in (distance,
-// index) order, which is what that code is after.  The vote is the reference's (:54-90),
-// including its always-true tie test, which retries with k-1 down to 1.
+// index) order, which is what that code is after.  The vote (:54-90) is taken in closed form, below.
 #define KNN_MAX_K 64
 __device__ __forceinline__ float knn_distance(const float *a, const float *b, int A) {
     float sum = 0;
@@ -350,29 +349,15 @@ __device__ __forceinline__ bool knn_before(float d1, int i1, float d2, int i2) {
     if (!n1 && d1 != d2) return d1 < d2;
     return i1 < i2;
 }
-__device__ inline int knn_vote(const int *indexes, const float *train, int k, int A) {
-    for (;;) {
-        int classVotes[32];
-        bool duplicate = false;
-        int finalClass = 0, mostVotes = 0;
-        for (int i = 0; i < 32; i++) classVotes[i] = 0;
-        for (int i = 0; i < k; i++) {
-            const int c = (int)train[(long long)indexes[i] * A + A - 1];
-            if (c >= 0 && c < 32) classVotes[c] += 1;  // the reference indexes out of bounds otherwise
-        }
-        for (int i = 0; i < 32; i++)
-            if (classVotes[i] > mostVotes) {
-                finalClass = i;
-                mostVotes = classVotes[i];
-            }
-        for (int i = 0; i < 32; i++)
-            if (classVotes[i] == mostVotes && classVotes[i] > 0) duplicate = true;
-        if (duplicate && (k - 1) > 0) {
-            k = k - 1;
-            continue;
-        }
-        return finalClass;
-    }
+// The reference's vote (:54-90) counts the classes of the k nearest rows, takes the first class with the most
+// votes, then asks whether any class has that many votes -- which the winner itself always has -- and if so
+// starts over with k - 1 as long as k - 1 > 0.  Every call therefore ends at k = 1, and the answer is the class of
+// the nearest row alone (class 0 when that label lies outside the 32 counters, where the reference would write
+// out of bounds, and for k < 1, where nothing is counted).
+__device__ inline int knn_vote(const int *nearest, const float *train, int k, int A) {
+    if (k < 1) return 0;
+    const int label = (int)train[(long long)nearest[0] * A + A - 1];
+    return (label >= 0 && label < 32) ? label : 0;
 }
 __global__ __launch_bounds__(64) void knn_kernel(const float *__restrict__ train, const float *__restrict__ test, int numTrain,
                                                  int numTest, int A, int k, int32_t *__restrict__ predictions) {

@@ -474,6 +474,27 @@ static int make_sp_sparse(iak_pipeline *p, int level, const uint8_t *code_plane)
     return 0;
 }
 
+// Is "the Sobel of a 0 / 255 image is non-zero" what the bit-mask run computes for it (iak_morph_bits.hpp: one
+// of the two gradients positive)?  Checked once per process against the Sobel kernel's own 512 results.
+static bool sobel_as_bits_verified() {
+    static int state = -1;  // -1 not tried, 0 no, 1 yes
+    if (state >= 0) return state == 1;
+    if (getenv("IAK_NO_MORPH_BITS")) return false;
+    iak_op sobel{};
+    sobel.type = IAK_OP_SOBEL;
+    BinTable bt;
+    if (eval_binary_table(sobel, &bt) != 0) return false;  // not decided: try again with the next pipeline
+    bool same = true;
+    for (int idx = 0; idx < 512 && same; idx++) {
+        auto px = [&](int i, int j) { return (idx >> (3 * i + j)) & 1; };  // row offset i - 1, column offset j - 1
+        const int right = px(0, 2) + 2 * px(1, 2) + px(2, 2), left = px(0, 0) + 2 * px(1, 0) + px(2, 0);
+        const int below = px(2, 0) + 2 * px(2, 1) + px(2, 2), above = px(0, 0) + 2 * px(0, 1) + px(0, 2);
+        same = (bt.v[idx] != 0) == (right > left || below > above);
+    }
+    state = same ? 1 : 0;
+    return same;
+}
+
 static int plan(iak_pipeline *p) {
     p->groups.clear();
     Group g0;
@@ -571,10 +592,24 @@ static int plan(iak_pipeline *p) {
             };
             const bool one_threshold = g.chain.n == 1 && (p->ops[i - 1].op.type == IAK_OP_OTSU ||
                                                           (p->ops[i - 1].op.type == IAK_OP_THRESHOLD && p->ops[i - 1].op.iparam >= 0));
-            if (p->mode == IAK_PIPE_FUSED && one_threshold && i < n && is_morph3(i) &&
-                p->W % 16 == 0 && (long long)p->W * ((long long)p->H + 8) < (1LL << 30)) {
-                int run = 0;
-                while (i + run < n && run < 3 && is_morph3(i + run)) run++;
+            // A Sobel between the threshold and the erosions / dilations joins the run when only "is it non-zero"
+            // of its result is ever looked at: a dilation behind it in the run, rows of whole 32-pixel words (the
+            // pass that takes it), and its 512 results on 0 / 255 neighbourhoods -- from the Sobel kernel
+            // itself -- non-zero exactly where the run's formula says so.
+            auto is_stage = [&](int k) {
+                return is_morph3(k) || (p->ops[k].op.type == IAK_OP_SOBEL && p->W % 32 == 0 && sobel_as_bits_verified());
+            };
+            int run = 0;
+            if (p->mode == IAK_PIPE_FUSED && one_threshold && p->W % 16 == 0 && (long long)p->W * ((long long)p->H + 8) < (1LL << 30)) {
+                while (i + run < n && run < 3 && is_stage(i + run)) run++;
+                for (int k = 0; k < run; k++) {
+                    if (p->ops[i + k].op.type != IAK_OP_SOBEL) continue;
+                    bool dilate_behind = false;
+                    for (int q = k + 1; q < run; q++) dilate_behind = dilate_behind || p->ops[i + q].op.type == IAK_OP_DILATE;
+                    if (!dilate_behind) run = k;  // the run ends in front of it
+                }
+            }
+            if (run >= 1) {
                 g.kind = G_MORPH;
                 g.op_index = i;
                 g.n_ops = run;

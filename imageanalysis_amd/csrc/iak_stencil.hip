@@ -15,6 +15,7 @@
 #include "iak_stencil_ops.hpp"
 #include "iak_stencil_tiled.hpp"
 #include "iak_morph_chain.hpp"
+#include "iak_morph_bits.hpp"
 #include "iak_morph_rows.hpp"
 #include "iak_median_bits.hpp"
 
@@ -418,6 +419,27 @@ int morph_chain3(const iak_op *ops, int n, const uint8_t *in, uint8_t *out, int 
                  long long out_stride, uint32_t *hist, const uint16_t *tables, void *stream, bool hist_cleared) {
     if (check_image_args(in, out, W, H, B, in_stride, out_stride)) return IAK_E_ARG;
     if (n < (tables ? 1 : 2) || n > MC_MAX_OPS) return IAK_E_UNSUPPORTED;
+    // 32 pixels per register where the run's output is two-valued and the rows are whole words; the only form
+    // that takes a Sobel stage
+    MorphBitsDesc db;
+    db.n = n;
+    bool any_sobel = false;
+    for (int k = 0; k < MBS_MAX_OPS; k++) { db.mask[k] = 0; db.kind[k] = MBS_ERODE; }
+    for (int k = 0; k < n; k++) {
+        const iak_op &o = ops[k];
+        if (o.type == IAK_OP_SOBEL) {
+            db.kind[k] = MBS_SOBEL;
+            any_sobel = true;
+            continue;
+        }
+        if ((o.type != IAK_OP_ERODE && o.type != IAK_OP_DILATE) || o.kW != 3 || o.kH != 3 || !o.ikernel) return IAK_E_UNSUPPORTED;
+        db.mask[k] = se_mask3(o.ikernel);
+        db.kind[k] = o.type == IAK_OP_DILATE ? MBS_DILATE : MBS_ERODE;
+    }
+    if (any_sobel || !getenv("IAK_NO_MORPH_BITS")) {
+        const int rc = launch_morph_bits(in, out, W, H, B, in_stride, out_stride, db, hist, tables, as_stream(stream), hist_cleared);
+        if (rc != IAK_E_UNSUPPORTED || any_sobel) return rc;
+    }
     MorphChainDesc d;
     d.n = n;
     for (int k = 0; k < MC_MAX_OPS; k++) { d.mask[k] = 0; d.dilate[k] = 0; }
