@@ -20,6 +20,7 @@
 #include "iak_stencil_ops.hpp"
 
 #include <new>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -477,9 +478,9 @@ static int make_sp_sparse(iak_pipeline *p, int level, const uint8_t *code_plane)
 // Is "the Sobel of a 0 / 255 image is non-zero" what the bit-mask run computes for it (iak_morph_bits.hpp: one
 // of the two gradients positive)?  Checked once per process against the Sobel kernel's own 512 results.
 static bool sobel_as_bits_verified() {
-    static int state = -1;  // -1 not tried, 0 no, 1 yes
-    if (state >= 0) return state == 1;
     if (getenv("IAK_NO_MORPH_BITS")) return false;
+    static std::atomic<int> state{-1};  // -1 not tried, 0 no, 1 yes
+    if (state.load() >= 0) return state.load() == 1;
     iak_op sobel{};
     sobel.type = IAK_OP_SOBEL;
     BinTable bt;
@@ -491,7 +492,7 @@ static bool sobel_as_bits_verified() {
         const int below = px(2, 0) + 2 * px(2, 1) + px(2, 2), above = px(0, 0) + 2 * px(0, 1) + px(0, 2);
         same = (bt.v[idx] != 0) == (right > left || below > above);
     }
-    state = same ? 1 : 0;
+    state.store(same ? 1 : 0);
     return same;
 }
 

@@ -108,6 +108,15 @@ CHAINS = {
                 {"type": O.OP_AVERAGE, "kW": 3, "kH": 3, "fkernel": [1.0] * 9},
                 {"type": O.OP_LINEAR, "kW": 3, "kH": 3, "fkernel": GAUSS16},
                 {"type": O.OP_AVERAGE, "kW": 3, "kH": 3, "fkernel": [0.3, -0.2, 0.1, 0.7, 1.1, -0.4, 0.25, 0.05, 0.6]}],
+    # a Sobel between a threshold and a dilation: only its being non-zero is looked at, on bit masks
+    "thr+sobel+dilate": [{"type": O.OP_THRESHOLD, "iparam": 120}, {"type": O.OP_SOBEL},
+                         {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": CROSS}],
+    "otsu+dilate+sobel+dilate": [{"type": O.OP_OTSU}, {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": [1, 0, 0, 0, 1, 0, 0, 1, 1]},
+                                 {"type": O.OP_SOBEL}, {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": ONES9},
+                                 {"type": O.OP_MEDIAN, "kW": 3, "kH": 3, "ikernel": ONES9}],
+    "otsu+sobel+erode+dilate+sobel": [{"type": O.OP_OTSU}, {"type": O.OP_SOBEL}, {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": CROSS},
+                                      {"type": O.OP_DILATE, "kW": 3, "kH": 3, "ikernel": [0, 1, 1, 1, 1, 0, 0, 0, 1]}, {"type": O.OP_SOBEL}],
+    "otsu+sobel+erode": [{"type": O.OP_OTSU}, {"type": O.OP_SOBEL}, {"type": O.OP_ERODE, "kW": 3, "kH": 3, "ikernel": ONES9}],
     "big-stencils": [{"type": O.OP_LINEAR, "kW": 11, "kH": 11, "fkernel": [1.0 / 121] * 121},
                      {"type": O.OP_MEDIAN, "kW": 7, "kH": 7, "ikernel": [1] * 49}],
 }
@@ -148,13 +157,14 @@ def test_pipeline_matches_oracle(Pipeline, name, fused, W, H, kind):
     p.close()
 
 
-@pytest.mark.parametrize("name", ["P-A", "input.json", "sp+median", "big-stencils"])
+@pytest.mark.parametrize("name", ["P-A", "P-C", "input.json", "sp+median", "big-stencils", "thr+sobel+dilate", "otsu+dilate+erode"])
 @pytest.mark.parametrize("W,H,kind", [(768, 40, "C"), (64, 48, "U"), (1024, 43, "U")])
 def test_pipeline_with_the_specialised_kernels_switched_off(Pipeline, monkeypatch, name, W, H, kind):
     """IAK_NO_LGS (read when a pipeline is planned) sends look-up / Gaussian / salt-pepper runs to the generic fused
     kernel, IAK_NO_BITSLICE_MEDIAN (read per call) sends small all-ones medians to the column-histogram kernel,
-    IAK_NO_BITSLICE_BOX (read per call) sends box filters with sum-dependent taps to the integer-sum kernel: the same
-    images either way."""
+    IAK_NO_BITSLICE_BOX (read per call) sends box filters with sum-dependent taps to the integer-sum kernel,
+    IAK_NO_MORPH_BITS (read per call and when a pipeline is planned) sends runs of erosions / dilations to the
+    8-pixel-chunk kernel and keeps a Sobel out of them: the same images either way."""
     ops = CHAINS[name]
     rgb = synth.rgb_batch(kind, W, H, 2)
     x0, x1 = O.xorwow_planes(W * H)
@@ -166,6 +176,7 @@ def test_pipeline_with_the_specialised_kernels_switched_off(Pipeline, monkeypatc
     monkeypatch.setenv("IAK_NO_LGS", "1")
     monkeypatch.setenv("IAK_NO_BITSLICE_MEDIAN", "1")
     monkeypatch.setenv("IAK_NO_BITSLICE_BOX", "1")
+    monkeypatch.setenv("IAK_NO_MORPH_BITS", "1")
     p = Pipeline(W, H, 2, ops, fused=True)
     assert np.array_equal(p.run(dev).cpu().numpy(), want)
     p.close()
