@@ -76,12 +76,16 @@ static CompassLut make_compass_lut() {
 
 // One workgroup of 256 lanes per image, lane v = grey value v.
 // features[b] = {mean, std, area, (perimeter: later), mode, rangeMin, rangeMax};
-// counts[b] = 0; thr_out[b] = the Otsu threshold (the mask is pixel > threshold, imageAnalysis.cu:207-216).
+// counts[b] = 0; thr_out[b] = the Otsu threshold (the mask is pixel > threshold, imageAnalysis.cu:207-216), or
+// FEAT_EMPTY_MASK when no pixel lies above it: the mask is then all zero, so is its compass image, the perimeter
+// feature is 0 (written here) and the edge count has nothing to read (every two-valued image with both values present ends here: Otsu's threshold on
+// its one-bin histogram is 255).
 // The workgroup past the last image writes the edge count's tables (tables != nullptr).
+#define FEAT_EMPTY_MASK 256
 __global__ __launch_bounds__(256) void features_stats_kernel(const uint32_t *__restrict__ hist, int numPixels, int B,
                                                              float *__restrict__ features, unsigned long long *__restrict__ counts,
                                                              int32_t *__restrict__ thr_out, PerimeterTables *__restrict__ tables,
-                                                             CompassLut lut) {
+                                                             CompassLut lut, int mark_empty) {
     __shared__ BlockScratch bs;
     const int b = blockIdx.x, v = threadIdx.x;
     if (b == B) {  // uniform over the workgroup
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(256) void features_stats_kernel(const uint32_t *__r
         f[5] = lo_key < 0 ? -1.0f : (float)(255 - (int)lo_key);
         f[6] = hi_key < 0 ? -1.0f : (float)(int)hi_key;
         counts[b] = 0;
-        thr_out[b] = thr;
+        thr_out[b] = (above == 0 && mark_empty) ? FEAT_EMPTY_MASK : thr;
+        if (above == 0 && mark_empty) f[3] = 0.0f;  // the edge count's workgroups for this image leave at once
     }
 }
 
@@ -159,13 +164,16 @@ __global__ __launch_bounds__(256) void perimeter_bits_kernel(const uint8_t *__re
                                                              float *__restrict__ features) {
     __shared__ __attribute__((aligned(16))) PerimeterTables t;
     __shared__ uint32_t part[4];
+    const int b = blockIdx.y;
+    // an empty mask has an all-zero compass image: nothing to read, and the statistics kernel has written the
+    // feature (0) already (uniform over the workgroup)
+    if (thr[b] >= FEAT_EMPTY_MASK) return;
     {
         const u32x4 *from = reinterpret_cast<const u32x4 *>(tables);
         u32x4 *to = reinterpret_cast<u32x4 *>(&t);
         for (int i = threadIdx.x; i < (int)(sizeof(PerimeterTables) / 16); i += 256) to[i] = from[i];
     }
     __syncthreads();
-    const int b = blockIdx.y;
     const uint8_t *src = in + (long long)b * stride;
     const int N = W * H;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, N, 0x00020000);
@@ -442,7 +450,8 @@ static int features_one_pass(const uint8_t *img, int W, int H, int B, long long 
     }
     // also clears counts[0..B)
     static const CompassLut lut = make_compass_lut();
-    hipLaunchKernelGGL(features_stats_kernel, dim3(B + 1), dim3(256), 0, s, hist, (int)N, B, features, counts, thr, tables, lut);
+    hipLaunchKernelGGL(features_stats_kernel, dim3(B + 1), dim3(256), 0, s, hist, (int)N, B, features, counts, thr, tables, lut,
+                       getenv("IAK_NO_EMPTY_MASK_SKIP") ? 0 : 1);
     IAK_LAUNCH_CHECK();
     const long long items = (long long)(W >> 3) * ((H + 7) / 8);
     // two work items per lane: a workgroup's copy of the tables costs about a fifth of an item per lane
@@ -476,7 +485,7 @@ int iak_features(const uint8_t *img, int W, int H, int B, long long stride, cons
         hist = own_hist;
     }
     hipLaunchKernelGGL(features_stats_kernel, dim3(B), dim3(256), 0, s, hist, (int)N, B, features, counts, thr,
-                       (PerimeterTables *)nullptr, CompassLut());
+                       (PerimeterTables *)nullptr, CompassLut(), 0);
     IAK_LAUNCH_CHECK();
     // any other shape: the three passes of the reference, on workspace images
     const size_t img_bytes = ((size_t)B * (size_t)N + 255) & ~(size_t)255;

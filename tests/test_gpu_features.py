@@ -77,6 +77,29 @@ def test_features_match_oracle(ops, W, H, kind, with_hist):
         assert np.array_equal(got[b], want), (b, got[b], want)
 
 
+@pytest.mark.parametrize("W,H", [(64, 48), (768, 40), (37, 23)])
+def test_features_of_images_whose_mask_is_empty_or_full(ops, monkeypatch, W, H):
+    """Otsu's threshold on a two-valued image with both values present is the upper value: no pixel lies above it,
+    the mask is empty and the edge count has nothing to read (the kernel skips such images).  Mixed in one batch
+    with images that do have a mask, an all-255 image (mask = everything) and an all-zero one; the same with the
+    shortcut switched off."""
+    rs = np.random.default_rng(W + H)
+    imgs = synth.gray_batch("C", W, H, 7)
+    imgs[1] = (rs.random((H, W)) < 0.4) * np.uint8(255)          # 0 / 255
+    imgs[2] = np.where(rs.random((H, W)) < 0.7, 17, 200).astype(np.uint8)  # two grey levels
+    imgs[3] = 255
+    imgs[4] = 0
+    imgs[5] = 90                                                  # one grey level
+    x = torch.from_numpy(imgs).cuda()
+    want = np.stack([O.features(imgs[b]) for b in range(7)])
+    assert want[1][3] == 0 and want[1][2] == 0  # the empty mask: no perimeter, no area
+    got = ops.featureExtraction(x).cpu().numpy()
+    assert np.array_equal(got, want), (got, want)
+    monkeypatch.setenv("IAK_NO_EMPTY_MASK_SKIP", "1")
+    got = ops.featureExtraction(x).cpu().numpy()
+    assert np.array_equal(got, want), (got, want)
+
+
 def test_features_single_image_and_strided_batch(ops):
     W, H = 64, 32
     imgs = synth.gray_batch("C", W, H, 4)
