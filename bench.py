@@ -501,9 +501,18 @@ class Measurement:
         llc = tpx <= LLC_BYTES
         groups = []
         used_traffic = used_valu = False
+        # Feature extraction does not read an image whose Otsu mask is empty (its perimeter is 0 without looking:
+        # every two-valued image with both values present).  Such an image has area 0 and perimeter 0 in the
+        # results of the last step; the group's moved bytes count the others only.
+        features_read_frac = 1.0
+        if self.feats is not None:
+            f = self.feats.cpu()
+            features_read_frac = 1.0 - float(((f[:, 2] == 0) & (f[:, 3] == 0)).float().mean())
+        moved = [mv * features_read_frac if n == "features" else mv for (n, _, _, _), mv in zip(self.groups, moved)] \
+            if self.groups else list(moved)
         for gi, ((n, ms, stage_b, mm), mv) in enumerate(zip(self.groups, moved)):
             g = {"name": n, "kernel": kernel_of.get(n, n), "ms": round(ms, 4), "kernel_ms": round(mm, 4), "images": timed_images,
-                 "moved_bytes_per_px": mv, "stagewise_bytes_per_px": stage_b,
+                 "moved_bytes_per_px": round(mv, 3) if n == "features" else mv, "stagewise_bytes_per_px": stage_b,
                  "input_from": "hbm" if (gi == 0 or not llc) else "infinity-cache"}
             if mm > 0:
                 gbps = mv * tpx / (mm * 1e-3) / 1e9
@@ -525,11 +534,13 @@ class Measurement:
                 if tr and tr.get("batch") == B and tr.get("kernel") == g["kernel"]:
                     g["traffic_bytes_per_launch"] = tr["hbm_bytes_per_launch"]
                     used_traffic = True
+            if n == "features" and features_read_frac < 1.0:
+                g["images_read_frac"] = round(features_read_frac, 4)
             groups.append(g)
         moved_total = sum(moved)
         line = {
             "value": round(value, 1), "ms_per_step": round(dt / steps * 1e3, 4),
-            "pipeline_moved_bytes_per_px": moved_total,
+            "pipeline_moved_bytes_per_px": round(moved_total, 3) if self.feats is not None else moved_total,
             # fraction of HBM peak on the bytes the executed plan has to move (<= 1 by construction)
             "pipeline_hbm_frac_moved_bytes": round(value * 1e6 / world * moved_total / (HBM_PEAK_GBS * 1e9), 4),
             "pipeline_stagewise_bytes_per_px": self.stagewise_bytes,
