@@ -257,8 +257,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
 }
 
-// KW x KW box of weight w with sum-dependent taps (BOX_SPECIAL), linear filter only; images whose rows start at
-// multiples of 4 bytes.  IAK_E_UNSUPPORTED otherwise.
+// KW x KW box (KW = 5 .. 13) of weight w with sum-dependent taps (BOX_SPECIAL), linear filter only; images whose
+// rows start at multiples of 4 bytes.  IAK_E_UNSUPPORTED otherwise (15 x 15 would keep its remembered rows in
+// scratch memory: the loop is too long to unroll).
 static int launch_bitslice_box(const uint8_t *in, uint8_t *out, int W, int H, int B, long long in_stride, long long out_stride,
                                int kW, int kH, float w, const BoxSpecial &sp, hipStream_t s) {
     if (kW != kH || W % 4 != 0 || reinterpret_cast<uintptr_t>(in) % 4 != 0 || reinterpret_cast<uintptr_t>(out) % 4 != 0 ||
@@ -298,7 +299,6 @@ static int launch_bitslice_box(const uint8_t *in, uint8_t *out, int W, int H, in
     BSB_CASE(7)
     BSB_CASE(9)
     BSB_CASE(13)
-    BSB_CASE(15)
 #undef BSB_CASE
     return IAK_E_UNSUPPORTED;
 }
