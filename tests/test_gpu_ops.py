@@ -313,6 +313,28 @@ def test_box_filters_whose_taps_depend_on_the_running_sum(ops, kW, kH, w, W, H):
     each(lambda x: ops.averageFilter(x, k, kW, kH), lambda x: O.average(x, k, kW, kH), imgs)
 
 
+def test_box_filter_with_sum_dependent_taps_in_a_strided_batch(ops):
+    """The bit-sliced box kernel on images inside a larger allocation whose gaps hold 255s: rows past an image's
+    end must read as zeros, not as the gap or the next image, and nothing is written between the images."""
+    import ctypes as C
+    from imageanalysis_amd import lib as L
+    W, H, B = 132, 41, 3
+    rs = np.random.default_rng(5)
+    imgs = rs.choice([0, 120, 121, 122, 241, 242, 243, 255], size=(B, H, W)).astype(np.uint8)
+    stride = W * H + 76
+    buf = torch.full((B * stride + 64,), 255, dtype=torch.uint8, device="cuda")
+    buf[: B * stride].view(B, stride)[:, : W * H] = torch.from_numpy(imgs.reshape(B, -1)).cuda()
+    out = torch.zeros_like(buf)
+    k = np.full(121, 1.0 / 121, np.float32)
+    rc = L.load().iak_linear(buf.data_ptr(), out.data_ptr(), W, H, B, stride, stride, k.ctypes.data_as(C.c_void_p), 11, 11, 0, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = out[: B * stride].view(B, stride)
+    for b in range(B):
+        assert np.array_equal(got[b, : W * H].cpu().numpy().reshape(H, W), O.linear(imgs[b], k, 11, 11)), b
+    assert int(got[:, W * H:].max()) == 0
+
+
 @pytest.mark.parametrize("kW,kH", [(5, 5), (7, 7), (15, 15), (3, 9), (9, 3), (1, 5), (5, 1), (15, 17)])
 @pytest.mark.parametrize("W,H,kind", [(200, 70, "C"), (131, 150, "U"), (64, 33, "K"), (300, 20, "C"), (5, 9, "U")])
 def test_median_sliding_histogram(ops, kW, kH, W, H, kind):
